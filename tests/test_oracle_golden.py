@@ -1,0 +1,49 @@
+"""CPU: the oracle restatement vs the committed outputs of the LIVE reference
+(tests/golden/*.npz, made by oracle/make_golden.py from /root/reference)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import synth
+from oracle.make_golden import CASES, GOLD, case_inputs
+from oracle.vallex_oracle import VallexOracle
+
+FAST = [n for n in CASES if n.startswith("nl2_")]
+
+
+def run_oracle(name, taps=None):
+    c = CASES[name]
+    sd = synth.vallex_state_dict(c["num_layers"], c["seed"], c["eos_gain"])
+    orc = VallexOracle(sd, c["num_layers"])
+    a, t, text, pl, langs = case_inputs(c)
+    us = None if c["useed"] is None else synth.uniforms(4096, 1, c["useed"])[:, 0]
+    return orc.inference(text, np.array([text.shape[-1]]), a, t.shape[-1], top_k=c["top_k"],
+                         temperature=c.get("temperature", 1.0), prompt_language=pl, text_language=langs,
+                         uniforms=us, force_eos_at=c["force_eos_at"], taps=taps)
+
+
+@pytest.mark.parametrize("name", FAST)
+def test_oracle_matches_reference_tokens(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    taps = {}
+    codes = run_oracle(name, taps)
+    assert codes.shape == g["codes"].shape
+    np.testing.assert_array_equal(codes, g["codes"])          # bit-exact ids, all 8 codebooks
+    ar = np.stack([l.numpy() for l in taps["ar_logits"][: g["ar_logits"].shape[0]]])
+    np.testing.assert_allclose(ar, g["ar_logits"], atol=2e-4, rtol=0)
+    np.testing.assert_allclose(taps["nar_logits"][0][:16].numpy(), g["nar_logits0"], atol=5e-3, rtol=0)
+
+
+def test_oracle_matches_reference_12_layers():
+    name = "nl12_c1_short"
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    np.testing.assert_array_equal(run_oracle(name), g["codes"])
+
+
+def test_synthetic_state_dict_layout():
+    sd = synth.vallex_state_dict(12, 0)
+    assert len(sd) == 374
+    n_ar = sum(v.size for k, v in sd.items() if k.startswith("ar_decoder."))
+    assert n_ar == 151_156_736
+    assert sd["nar_predict_layers.0.weight"] is sd["nar_audio_embeddings.2.word_embeddings.weight"]
