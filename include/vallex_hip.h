@@ -1,0 +1,127 @@
+/* vallex_hip.h -- C ABI of the MI355X-native VALL-E X inference hot path (libvallex_hip.so).
+ *
+ * The reference (Plachtaa/VALL-E-X) has no FFI or plugin interface: its drop-in boundary is the Python API
+ * (utils/generation.py:50,92,155 and models/vallex.py:458).  The package `vall-e-x_amd/` keeps those Python
+ * signatures and binds THIS header through ctypes; each entry point below cites the reference code it replaces
+ * (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; host pointers unless stated; the library owns all device memory inside an
+ *     opaque context (weights, KV arena, activations) and one HIP stream per context;
+ *   - every function returns 0 on success or a negative VX_E* code; vx_last_error() gives the message;
+ *   - a context is not thread-safe; different contexts (one per GPU / per host thread) are independent;
+ *   - token ids are int32 on the way in (max id 2047) and int64 on the way out, like the reference's LongTensor.
+ */
+#ifndef VALLEX_HIP_H
+#define VALLEX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VX_OK 0
+#define VX_EINVAL (-1)   /* bad argument / shape (reference: AssertionError, models/vallex.py:488-493) */
+#define VX_EHIP (-2)     /* HIP runtime failure (no GPU, OOM, launch error) */
+#define VX_ESTATE (-3)   /* call order violated (e.g. infer before vx_finalize_weights) */
+#define VX_ENOTFOUND (-4)/* unknown tensor name (reference: load_state_dict(strict=True) unexpected key) */
+
+typedef struct vx_ctx vx_ctx;
+
+/* Model/arena geometry.  d_model=1024, 16 heads, FFN 4096, 8 codebooks are fixed by the kernels
+ * (macros.py:1-6, utils/generation.py:67-78); the layer count is configurable so tests can run reduced stacks. */
+typedef struct vx_config {
+  int32_t num_layers;      /* 12 for the shipped checkpoint */
+  int32_t max_batch;       /* rows per vx_infer call; AR runs in micro-batches of <= 32 rows */
+  int32_t max_text;        /* max text ids per row (prompt text + text), S */
+  int32_t max_prompt;      /* max prompt frames per row, Tp */
+  int32_t max_new;         /* max generated frames per row (the reference cap is 16*S, models/vallex.py:577) */
+  int32_t use_graph;       /* 1: replay the AR step as a hipGraph */
+  int32_t with_vocos;      /* 1: allocate the Vocos head */
+  int32_t debug_taps;      /* 1: keep per-layer activations for vx_read_tap */
+} vx_config;
+
+/* ---- lifetime -------------------------------------------------------------------------------------------
+ * replaces: model construction + .to(device) in preload_models(), utils/generation.py:67-89 */
+int vx_create(int device_id, const vx_config* cfg, vx_ctx** out);
+void vx_destroy(vx_ctx* ctx);
+const char* vx_last_error(const vx_ctx* ctx);   /* ctx may be NULL: last error of a failed vx_create */
+int vx_synchronize(vx_ctx* ctx);
+
+/* ---- weights --------------------------------------------------------------------------------------------
+ * replaces: VALLE.load_state_dict(checkpoint["model"], strict=True), utils/generation.py:79-83, and
+ * Vocos.from_pretrained, utils/generation.py:89.  `name` is the reference state-dict key,
+ * Vocos tensors are prefixed "vocos." + their key in the vocos package.  fp32, C-contiguous, copied. */
+int vx_load_tensor(vx_ctx* ctx, const char* name, const float* data, const int64_t* shape, int32_t ndim);
+/* checks that all 374 (for 12 layers) keys arrived, builds packed decode images, the positional table
+ * (modules/embedding.py:75-91) and the per-stage AdaLN projections (modules/transformer.py:96-100). */
+int vx_finalize_weights(vx_ctx* ctx);
+
+/* ---- batch descriptor -------------------------------------------------------------------------------------
+ * One row = one utterance = one reference `VALLE.inference(x, x_lens, y, enroll_x_lens, ...)` call. */
+typedef struct vx_batch {
+  int32_t batch;
+  const int32_t* text_ids;      /* [batch][text_stride]   x: prompt text ids ++ text ids (utils/generation.py:133) */
+  const int32_t* text_lang;     /* [batch][text_stride]   per-token MODEL language id en0/zh1/ja2 (models/vallex.py:439-443,
+                                   499-505): first enroll_len entries = prompt_language, rest = text_language */
+  int32_t text_stride;
+  const int32_t* text_lens;     /* [batch]  x_lens */
+  const int32_t* prompt_codes;  /* [batch][prompt_stride][8]   y (audio prompt), values 0..1023 */
+  int32_t prompt_stride;
+  const int32_t* prompt_lens;   /* [batch]  y.shape[1] */
+} vx_batch;
+
+/* topk_sampling arguments (models/vallex.py:836-853) + reproducibility hooks */
+typedef struct vx_sampling {
+  int32_t top_k;                /* <= 0: no filtering (API default -100); 1: greedy */
+  float temperature;            /* > 0 */
+  const float* uniforms;        /* optional [uniforms_steps][batch] in [0,1): inverse-CDF draws replacing
+                                   torch.multinomial (models/vallex.py:850); NULL -> counter-based RNG from `seed` */
+  int32_t uniforms_steps;
+  uint64_t seed;
+  int32_t force_eos_at;         /* >= 0: the (n+1)-th sample is forced to EOS (benchmark stand-in for a trained
+                                   model's termination; -1 = off) */
+  int32_t sync_every;           /* host polls the device EOS flags every n steps (reference: every step,
+                                   models/vallex.py:574-578); <= 0 -> 8 */
+} vx_sampling;
+
+/* ---- the hot path ---------------------------------------------------------------------------------------- */
+/* replaces: VALLE.inference AR loop + 7 NAR stages, models/vallex.py:458-686.
+ * out_codes [batch][out_stride][8] int64 (row b valid for out_lens[b] frames), out_lens [batch]. */
+int vx_infer(vx_ctx* ctx, const vx_batch* b, const vx_sampling* s, int64_t* out_codes, int32_t out_stride,
+             int32_t* out_lens);
+
+/* replaces: vocos.codes_to_features + vocos.decode(features, bandwidth_id), utils/generation.py:148-150.
+ * codes [batch][codes_stride][8] int64, lens [batch] frames; audio [batch][audio_stride] fp32, 320*len samples each. */
+int vx_vocos_decode(vx_ctx* ctx, const int64_t* codes, int32_t codes_stride, const int32_t* lens, int32_t batch,
+                    int32_t bandwidth_id, float* audio, int64_t audio_stride);
+
+/* ---- step-level entries (kernel-level parity tests; same kernels as vx_infer) ---------------------------- */
+/* first ar_decoder.infer call (models/vallex.py:528-562): embeds, runs the prefix-LM prefill, fills the KV arena,
+ * leaves the logits of the last row available.  batch <= 32. */
+int vx_ar_prefill(vx_ctx* ctx, const vx_batch* b);
+/* logits of the newest position, [batch][1025] (ar_predict_layer, models/vallex.py:568) */
+int vx_ar_logits(vx_ctx* ctx, float* out);
+/* teacher-forced decode step: append tokens[b] (as if sampled) and run one cached step (models/vallex.py:552-562) */
+int vx_ar_step(vx_ctx* ctx, const int32_t* tokens);
+/* NAR stages only (models/vallex.py:600-686): codes0 [batch][codes0_stride] first-codebook ids, lens [batch] */
+int vx_nar(vx_ctx* ctx, const vx_batch* b, const int32_t* codes0, int32_t codes0_stride, const int32_t* lens,
+           int64_t* out_codes, int32_t out_stride);
+/* copy a named debug buffer to the host (needs cfg.debug_taps); returns the number of floats copied or < 0 */
+int64_t vx_read_tap(vx_ctx* ctx, const char* name, float* dst, int64_t max_floats);
+
+/* ---- measurement ------------------------------------------------------------------------------------------
+ * HIP-event timing of kernel classes on the context's own stream (bench.py roofline leg).
+ * which: 0 = dec_attn (KV streaming), 1 = skinny GEMMs, 2 = full-seq GEMM, 3 = full-seq attention.
+ * vx_prof_enable(1) makes the AR step run un-graphed with an event pair around each launch of every class. */
+int vx_prof_enable(vx_ctx* ctx, int32_t on);
+int vx_prof_get(vx_ctx* ctx, int32_t which, double* total_ms, int64_t* launches, double* algo_bytes);
+int vx_prof_reset(vx_ctx* ctx);
+/* counters of the last vx_infer: AR steps run, generated frames, AR / NAR wall milliseconds (stream-synchronised) */
+int vx_last_stats(vx_ctx* ctx, int64_t* ar_steps, int64_t* frames, double* ar_ms, double* nar_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VALLEX_HIP_H */

@@ -1,0 +1,248 @@
+"""ctypes binding of include/vallex_hip.h -- the only way the Python layer reaches the GPU.
+
+There is deliberately NO CPU fallback: if libvallex_hip.so is missing or no HIP device is present the calls
+raise (VallexHipError / OSError); nothing here imports oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvallex_hip.so")
+
+VX_OK, VX_EINVAL, VX_EHIP, VX_ESTATE, VX_ENOTFOUND = 0, -1, -2, -3, -4
+
+
+class VallexHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"vallex_hip error {code}: {msg}")
+        self.code = code
+
+
+class vx_config(C.Structure):
+    _fields_ = [("num_layers", C.c_int32), ("max_batch", C.c_int32), ("max_text", C.c_int32),
+                ("max_prompt", C.c_int32), ("max_new", C.c_int32), ("use_graph", C.c_int32),
+                ("with_vocos", C.c_int32), ("debug_taps", C.c_int32)]
+
+
+class vx_batch(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("text_ids", C.POINTER(C.c_int32)), ("text_lang", C.POINTER(C.c_int32)),
+                ("text_stride", C.c_int32), ("text_lens", C.POINTER(C.c_int32)),
+                ("prompt_codes", C.POINTER(C.c_int32)), ("prompt_stride", C.c_int32),
+                ("prompt_lens", C.POINTER(C.c_int32))]
+
+
+class vx_sampling(C.Structure):
+    _fields_ = [("top_k", C.c_int32), ("temperature", C.c_float), ("uniforms", C.POINTER(C.c_float)),
+                ("uniforms_steps", C.c_int32), ("seed", C.c_uint64), ("force_eos_at", C.c_int32),
+                ("sync_every", C.c_int32)]
+
+
+# every symbol include/vallex_hip.h declares (tests/test_abi.py checks the library exports exactly these)
+SYMBOLS = ["vx_create", "vx_destroy", "vx_last_error", "vx_synchronize", "vx_load_tensor", "vx_finalize_weights",
+           "vx_infer", "vx_vocos_decode", "vx_ar_prefill", "vx_ar_logits", "vx_ar_step", "vx_nar", "vx_read_tap",
+           "vx_prof_enable", "vx_prof_get", "vx_prof_reset", "vx_last_stats"]
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the in-tree library (built by __graft_entry__.build() / vall-e-x_amd/_build.py).  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    ctx = C.c_void_p
+    lib.vx_create.argtypes = [C.c_int, P(vx_config), P(ctx)]
+    lib.vx_destroy.argtypes = [ctx]
+    lib.vx_destroy.restype = None
+    lib.vx_last_error.argtypes = [ctx]
+    lib.vx_last_error.restype = C.c_char_p
+    lib.vx_synchronize.argtypes = [ctx]
+    lib.vx_load_tensor.argtypes = [ctx, C.c_char_p, P(C.c_float), P(C.c_int64), C.c_int32]
+    lib.vx_finalize_weights.argtypes = [ctx]
+    lib.vx_infer.argtypes = [ctx, P(vx_batch), P(vx_sampling), P(C.c_int64), C.c_int32, P(C.c_int32)]
+    lib.vx_vocos_decode.argtypes = [ctx, P(C.c_int64), C.c_int32, P(C.c_int32), C.c_int32, C.c_int32, P(C.c_float),
+                                    C.c_int64]
+    lib.vx_ar_prefill.argtypes = [ctx, P(vx_batch)]
+    lib.vx_ar_logits.argtypes = [ctx, P(C.c_float)]
+    lib.vx_ar_step.argtypes = [ctx, P(C.c_int32)]
+    lib.vx_nar.argtypes = [ctx, P(vx_batch), P(C.c_int32), C.c_int32, P(C.c_int32), P(C.c_int64), C.c_int32]
+    lib.vx_read_tap.argtypes = [ctx, C.c_char_p, P(C.c_float), C.c_int64]
+    lib.vx_read_tap.restype = C.c_int64
+    lib.vx_prof_enable.argtypes = [ctx, C.c_int32]
+    lib.vx_prof_get.argtypes = [ctx, C.c_int32, P(C.c_double), P(C.c_int64), P(C.c_double)]
+    lib.vx_prof_reset.argtypes = [ctx]
+    lib.vx_last_stats.argtypes = [ctx, P(C.c_int64), P(C.c_int64), P(C.c_double), P(C.c_double)]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("vx_destroy", "vx_last_error", "vx_read_tap"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _ptr(a: np.ndarray, ty):
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+class Batch:
+    """Host-side batch descriptor: one row per utterance (= one reference VALLE.inference call)."""
+
+    def __init__(self, texts: Sequence[np.ndarray], text_langs: Sequence[np.ndarray], prompts: Sequence[np.ndarray]):
+        n = len(texts)
+        assert n == len(text_langs) == len(prompts) and n > 0
+        self.n = n
+        self.text_lens = np.array([len(t) for t in texts], np.int32)
+        self.prompt_lens = np.array([p.shape[0] for p in prompts], np.int32)
+        ts, ps = max(1, int(self.text_lens.max())), max(1, int(self.prompt_lens.max()))
+        self.text_ids = np.zeros((n, ts), np.int32)
+        self.text_lang = np.zeros((n, ts), np.int32)
+        self.prompt_codes = np.zeros((n, ps, 8), np.int32)
+        for i in range(n):
+            self.text_ids[i, : len(texts[i])] = texts[i]
+            self.text_lang[i, : len(texts[i])] = text_langs[i]
+            if prompts[i].shape[0]:
+                self.prompt_codes[i, : prompts[i].shape[0]] = prompts[i]
+        self.c = vx_batch(n, _ptr(self.text_ids, C.c_int32), _ptr(self.text_lang, C.c_int32), ts,
+                          _ptr(self.text_lens, C.c_int32), _ptr(self.prompt_codes, C.c_int32), ps,
+                          _ptr(self.prompt_lens, C.c_int32))
+
+
+class Engine:
+    """Owns one vx_ctx (one GPU).  Not thread-safe; create one per device / process."""
+
+    def __init__(self, device_id: int = 0, num_layers: int = 12, max_batch: int = 32, max_text: int = 512,
+                 max_prompt: int = 1024, max_new: int = 2048, use_graph: bool = True, with_vocos: bool = True,
+                 debug_taps: bool = False):
+        self.lib = load_library()
+        self.cfg = vx_config(num_layers, max_batch, max_text, max_prompt, max_new, int(use_graph), int(with_vocos),
+                             int(debug_taps))
+        self.ctx = C.c_void_p()
+        rc = self.lib.vx_create(device_id, C.byref(self.cfg), C.byref(self.ctx))
+        if rc != VX_OK:
+            msg = self.lib.vx_last_error(None).decode()
+            self.ctx = None
+            raise VallexHipError(rc, msg)
+        self.max_new = max_new
+        self.max_batch = max_batch
+        self.finalized = False
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.vx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int):
+        if rc < 0:
+            raise VallexHipError(rc, self.lib.vx_last_error(self.ctx).decode())
+        return rc
+
+    def load_tensor(self, name: str, arr: np.ndarray):
+        a = np.ascontiguousarray(arr, dtype=np.float32)
+        shape = (C.c_int64 * max(1, a.ndim))(*a.shape)
+        self._chk(self.lib.vx_load_tensor(self.ctx, name.encode(), _ptr(a, C.c_float), shape, a.ndim))
+
+    def finalize(self):
+        self._chk(self.lib.vx_finalize_weights(self.ctx))
+        self.finalized = True
+
+    def synchronize(self):
+        self._chk(self.lib.vx_synchronize(self.ctx))
+
+    @staticmethod
+    def _sampling(n, top_k, temperature, uniforms, seed, force_eos_at, sync_every):
+        u = None
+        s = vx_sampling(int(top_k), float(temperature), None, 0, int(seed), -1 if force_eos_at is None else int(force_eos_at),
+                        int(sync_every))
+        if uniforms is not None:
+            u = np.ascontiguousarray(uniforms, np.float32)
+            if u.ndim == 1:
+                u = u[:, None]
+            assert u.shape[1] == n, "uniforms must be [steps][batch]"
+            s.uniforms = _ptr(u, C.c_float)
+            s.uniforms_steps = u.shape[0]
+        return s, u
+
+    def infer(self, batch: Batch, top_k=-100, temperature=1.0, uniforms=None, seed=0, force_eos_at=None,
+              sync_every=8):
+        s, _keep = self._sampling(batch.n, top_k, temperature, uniforms, seed, force_eos_at, sync_every)
+        out = np.zeros((batch.n, self.max_new, 8), np.int64)
+        lens = np.zeros(batch.n, np.int32)
+        self._chk(self.lib.vx_infer(self.ctx, C.byref(batch.c), C.byref(s), _ptr(out, C.c_int64), self.max_new,
+                                    _ptr(lens, C.c_int32)))
+        return [out[i, : lens[i]].copy() for i in range(batch.n)]
+
+    def vocos_decode(self, codes: Sequence[np.ndarray], bandwidth_id: int = 2):
+        n = len(codes)
+        lens = np.array([c.shape[0] for c in codes], np.int32)
+        stride = max(1, int(lens.max()))
+        buf = np.zeros((n, stride, 8), np.int64)
+        for i, c in enumerate(codes):
+            buf[i, : c.shape[0]] = c
+        audio = np.zeros((n, stride * 320), np.float32)
+        self._chk(self.lib.vx_vocos_decode(self.ctx, _ptr(buf, C.c_int64), stride, _ptr(lens, C.c_int32), n,
+                                           int(bandwidth_id), _ptr(audio, C.c_float), stride * 320))
+        return [audio[i, : lens[i] * 320].copy() for i in range(n)]
+
+    # ---- step-level (tests) ----
+    def ar_prefill(self, batch: Batch):
+        self._chk(self.lib.vx_ar_prefill(self.ctx, C.byref(batch.c)))
+        self._nb = batch.n
+
+    def ar_logits(self) -> np.ndarray:
+        out = np.zeros((self._nb, 1025), np.float32)
+        self._chk(self.lib.vx_ar_logits(self.ctx, _ptr(out, C.c_float)))
+        return out
+
+    def ar_step(self, tokens):
+        t = np.ascontiguousarray(tokens, np.int32)
+        self._chk(self.lib.vx_ar_step(self.ctx, _ptr(t, C.c_int32)))
+
+    def nar(self, batch: Batch, codes0: Sequence[np.ndarray]):
+        lens = np.array([len(c) for c in codes0], np.int32)
+        stride = max(1, int(lens.max()))
+        c0 = np.zeros((batch.n, stride), np.int32)
+        for i, c in enumerate(codes0):
+            c0[i, : len(c)] = c
+        out = np.zeros((batch.n, stride, 8), np.int64)
+        self._chk(self.lib.vx_nar(self.ctx, C.byref(batch.c), _ptr(c0, C.c_int32), stride, _ptr(lens, C.c_int32),
+                                  _ptr(out, C.c_int64), stride))
+        return [out[i, : lens[i]].copy() for i in range(batch.n)]
+
+    def read_tap(self, name: str, n: int) -> np.ndarray:
+        out = np.zeros(n, np.float32)
+        got = self.lib.vx_read_tap(self.ctx, name.encode(), _ptr(out, C.c_float), n)
+        self._chk(int(got))
+        return out[: int(got)]
+
+    # ---- measurement ----
+    def prof_enable(self, on: bool):
+        self._chk(self.lib.vx_prof_enable(self.ctx, int(on)))
+
+    def prof_reset(self):
+        self._chk(self.lib.vx_prof_reset(self.ctx))
+
+    def prof_get(self, which: int):
+        ms, n, by = C.c_double(), C.c_int64(), C.c_double()
+        self._chk(self.lib.vx_prof_get(self.ctx, which, C.byref(ms), C.byref(n), C.byref(by)))
+        return ms.value, n.value, by.value
+
+    def last_stats(self):
+        a, f, am, nm = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
+        self._chk(self.lib.vx_last_stats(self.ctx, C.byref(a), C.byref(f), C.byref(am), C.byref(nm)))
+        return dict(ar_steps=a.value, frames=f.value, ar_ms=am.value, nar_ms=nm.value)

@@ -1,0 +1,1078 @@
+// Engine: context, weight ingest, arenas, launch sequences and the C ABI (include/vallex_hip.h).
+// Host-side counterpart of VALLE.inference (models/vallex.py:458-686) + the Vocos call of
+// utils/generation.py:148-150; every hot op is a hand-written gfx950 kernel from the sibling .hip files.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/vallex_hip.h"
+#include "vx_common.h"
+
+using namespace vx;
+
+namespace {
+
+std::string g_create_err;
+
+struct Tensor {
+  float* d = nullptr;
+  std::vector<int64_t> shape;
+  size_t n = 0;
+};
+
+struct LayerW {
+  const float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b, *n1_w, *n1_b, *n2_w, *n2_b;
+  float *in_wp = nullptr, *out_wp = nullptr, *l1_wp = nullptr, *l2_wp = nullptr;   // packed decode images (AR only)
+};
+
+struct ProfClass {
+  std::vector<hipEvent_t> ev;   // pairs
+  size_t used = 0;
+  double bytes = 0;
+};
+
+constexpr int SK_QKV = 4, SK_OUT = 4, SK_L1 = 4, SK_L2 = 8, SK_PRED = 4;
+constexpr int PRED_NPAD = 1056;
+
+}  // namespace
+
+struct vx_ctx {
+  vx_config cfg{};
+  int dev = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::map<std::string, Tensor> w;
+  bool finalized = false;
+  std::vector<void*> allocs;
+
+  // derived weights
+  int NL = 0;
+  float* pe = nullptr;
+  int pe_rows = 0;
+  std::vector<LayerW> ar, nar;
+  float* ada = nullptr;            // [7][2NL+1][2048]
+  float* pred_wp = nullptr;        // packed ar_predict_layer
+  const float** nar_tabs_dev = nullptr;
+  bool has_vocos = false;
+  float *vc_embed_w = nullptr, *vc_head_w = nullptr, *vc_head_b = nullptr, *vc_dft = nullptr, *vc_win2 = nullptr;
+
+  // geometry
+  int mbr = 0;                     // rows per micro-batch (<= 32)
+  int Tmax = 0;                    // KV rows per (row, head)
+  long Mmax = 0;                   // packed rows of a micro-batch on the full-sequence paths
+
+  // full-sequence arena
+  float *fx = nullptr, *fxn = nullptr, *fqkv = nullptr, *fatt = nullptr, *fffn = nullptr, *fyemb = nullptr,
+        *flogits = nullptr;
+  int* imeta = nullptr;            // device int scratch for row metadata
+  long imeta_cap = 0;
+  std::vector<int> hmeta;          // host staging for imeta
+
+  // decode arena
+  float *kc = nullptr, *vc = nullptr;      // [NL][mbr*16][Tmax][64]
+  float *dh = nullptr, *xp = nullptr, *xp_att = nullptr, *xp4 = nullptr;
+  float *p_qkv = nullptr, *p_o = nullptr, *p_f = nullptr, *p_logits = nullptr, *part_o = nullptr, *part_ml = nullptr;
+  float *d_logits = nullptr, *d_uniforms = nullptr;
+  long uniforms_cap = 0;
+  int *cur_tok = nullptr, *cur_pos = nullptr, *ctx_len = nullptr, *n_gen = nullptr, *active = nullptr,
+      *text_len = nullptr, *gen = nullptr, *force_tok = nullptr;
+  int gen_stride = 0;
+  int cur_batch = 0;
+  int nsplit = 1;
+  std::vector<int> h_L;            // prefill lengths of the current micro-batch
+
+  // graph
+  hipGraphExec_t graph_exec = nullptr;
+  std::string graph_sig;
+
+  // taps
+  std::map<std::string, Tensor> taps;
+
+  // profiling / stats
+  bool prof_on = false;
+  ProfClass prof[4];
+  int64_t st_steps = 0, st_frames = 0;
+  double st_ar_ms = 0, st_nar_ms = 0;
+
+  // vocos arena
+  float *vfeat = nullptr, *vcol = nullptr, *vx0 = nullptr, *vx1 = nullptr, *vhid = nullptr, *vo = nullptr,
+        *vreim = nullptr, *vframes = nullptr, *vaudio = nullptr;
+  long v_rows_cap = 0;
+};
+
+namespace {
+
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess) {                                                                            \
+      char _buf[512];                                                                                  \
+      snprintf(_buf, sizeof _buf, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      c->err = _buf;                                                                                   \
+      return VX_EHIP;                                                                                  \
+    }                                                                                                  \
+  } while (0)
+
+#define FAIL(code, ...)                         \
+  do {                                          \
+    char _buf[512];                             \
+    snprintf(_buf, sizeof _buf, __VA_ARGS__);   \
+    c->err = _buf;                              \
+    return (code);                              \
+  } while (0)
+
+template <typename T>
+int dev_alloc(vx_ctx* c, T** p, size_t count, bool zero = true) {
+  void* q = nullptr;
+  HIPCHK(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+  c->allocs.push_back(q);
+  if (zero) HIPCHK(hipMemsetAsync(q, 0, std::max<size_t>(count, 1) * sizeof(T), c->stream));
+  *p = reinterpret_cast<T*>(q);
+  return VX_OK;
+}
+
+const float* W(vx_ctx* c, const std::string& name) {
+  auto it = c->w.find(name);
+  return it == c->w.end() ? nullptr : it->second.d;
+}
+
+// ---- profiling helpers: an event pair around one launch --------------------------------------------------
+struct ProfScope {
+  vx_ctx* c;
+  int which;
+  bool on;
+  ProfScope(vx_ctx* c_, int w) : c(c_), which(w), on(c_->prof_on) {
+    if (!on) return;
+    ProfClass& p = c->prof[which];
+    if (p.used + 2 > p.ev.size()) {
+      for (int i = 0; i < 2; ++i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { on = false; return; }
+        p.ev.push_back(e);
+      }
+    }
+    (void)hipEventRecord(p.ev[p.used], c->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    ProfClass& p = c->prof[which];
+    (void)hipEventRecord(p.ev[p.used + 1], c->stream);
+    p.used += 2;
+  }
+};
+
+// ---- int metadata upload ---------------------------------------------------------------------------------
+int upload_meta(vx_ctx* c) {
+  if ((long)c->hmeta.size() > c->imeta_cap) FAIL(VX_EINVAL, "row metadata overflow (%zu > %ld)", c->hmeta.size(), c->imeta_cap);
+  HIPCHK(hipMemcpyAsync(c->imeta, c->hmeta.data(), c->hmeta.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  // the host vector is reused by the next call: make the copy complete first
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return VX_OK;
+}
+
+struct MetaBuilder {
+  vx_ctx* c;
+  explicit MetaBuilder(vx_ctx* c_) : c(c_) { c->hmeta.clear(); }
+  // reserve n ints, return offset
+  long add(const std::vector<int>& v) {
+    long off = (long)c->hmeta.size();
+    c->hmeta.insert(c->hmeta.end(), v.begin(), v.end());
+    while (c->hmeta.size() % 4) c->hmeta.push_back(0);
+    return off;
+  }
+  const int* dev(long off) const { return c->imeta + off; }
+};
+
+int tap_store(vx_ctx* c, const std::string& name, const float* src, size_t n) {
+  if (!c->cfg.debug_taps) return VX_OK;
+  Tensor& t = c->taps[name];
+  if (t.n < n) {
+    void* q = nullptr;
+    HIPCHK(hipMalloc(&q, n * sizeof(float)));
+    c->allocs.push_back(q);
+    t.d = reinterpret_cast<float*>(q);
+  }
+  t.n = n;
+  HIPCHK(hipMemcpyAsync(t.d, src, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  return VX_OK;
+}
+
+// ---- dense helpers -----------------------------------------------------------------------------------------
+void gemm(vx_ctx* c, const float* A, int lda, const float* Wt, int ldw, const float* bias, const float* resid, int ldr,
+          const float* colscale, float* C, int ldc, long M, int N, int K, int act, const int* gather = nullptr) {
+  GemmArgs g{};
+  g.A = A; g.lda = lda; g.W = Wt; g.ldw = ldw; g.bias = bias; g.resid = resid; g.ldr = ldr; g.colscale = colscale;
+  g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.act = act; g.row_gather = gather;
+  ProfScope ps(c, 2);
+  if (c->prof_on) c->prof[2].bytes += 2.0 * (double)M * N * K;      // flops for this class
+  launch_gemm_f32(g, c->stream);
+}
+
+// one pre-norm block on packed rows (modules/transformer.py:296-302 / :337-347) -- shared by AR prefill and NAR
+int full_layer(vx_ctx* c, const LayerW& L, long M, const int* seq_off, const int* seq_len, const int* prefix_len,
+               int batch, int max_len, const float* ada1, const float* ada2, float* kcl, float* vcl,
+               const int* row_b, const int* row_t, double attn_flops) {
+  launch_layernorm(c->fx, D_MODEL, c->fxn, D_MODEL, (int)M, D_MODEL, LN_EPS, L.n1_w, L.n1_b, ada1,
+                   ada1 ? ada1 + D_MODEL : nullptr, c->stream);
+  gemm(c, c->fxn, D_MODEL, L.in_w, D_MODEL, L.in_b, nullptr, 0, nullptr, c->fqkv, 3 * D_MODEL, M, 3 * D_MODEL, D_MODEL,
+       ACT_NONE);
+  if (kcl) launch_kv_scatter(c->fqkv, row_b, row_t, (int)M, kcl, vcl, c->Tmax, c->stream);
+  {
+    ProfScope ps(c, 3);
+    if (c->prof_on) c->prof[3].bytes += attn_flops;
+    launch_attn_full(c->fqkv, c->fatt, seq_off, seq_len, prefix_len, batch, max_len, c->stream);
+  }
+  gemm(c, c->fatt, D_MODEL, L.out_w, D_MODEL, L.out_b, c->fx, D_MODEL, nullptr, c->fx, D_MODEL, M, D_MODEL, D_MODEL,
+       ACT_NONE);
+  launch_layernorm(c->fx, D_MODEL, c->fxn, D_MODEL, (int)M, D_MODEL, LN_EPS, L.n2_w, L.n2_b, ada2,
+                   ada2 ? ada2 + D_MODEL : nullptr, c->stream);
+  gemm(c, c->fxn, D_MODEL, L.l1_w, D_MODEL, L.l1_b, nullptr, 0, nullptr, c->fffn, D_FF, M, D_FF, D_MODEL, ACT_RELU);
+  gemm(c, c->fffn, D_FF, L.l2_w, D_FF, L.l2_b, c->fx, D_MODEL, nullptr, c->fx, D_MODEL, M, D_MODEL, D_FF, ACT_NONE);
+  return VX_OK;
+}
+
+int check_batch(vx_ctx* c, const vx_batch* b, int max_rows) {
+  if (!c->finalized) FAIL(VX_ESTATE, "weights not finalized");
+  if (!b || b->batch <= 0 || b->batch > max_rows) FAIL(VX_EINVAL, "batch must be in 1..%d", max_rows);
+  for (int i = 0; i < b->batch; ++i) {
+    const int S = b->text_lens[i], Tp = b->prompt_lens[i];
+    if (S <= 0) FAIL(VX_EINVAL, "x_lens must be > 0 (models/vallex.py:493)");       // assert torch.all(x_lens > 0)
+    if (S > c->cfg.max_text || S > b->text_stride) FAIL(VX_EINVAL, "row %d: text length %d exceeds max_text", i, S);
+    if (Tp < 0 || Tp > c->cfg.max_prompt || Tp > b->prompt_stride)
+      FAIL(VX_EINVAL, "row %d: prompt length %d exceeds max_prompt", i, Tp);
+    for (int s = 0; s < S; ++s) {
+      const int id = b->text_ids[(long)i * b->text_stride + s], lg = b->text_lang[(long)i * b->text_stride + s];
+      if (id < 0 || id >= 2048) FAIL(VX_EINVAL, "row %d: text id %d out of range", i, id);
+      if (lg < 0 || lg > 2) FAIL(VX_EINVAL, "row %d: language id %d out of range", i, lg);
+    }
+    for (int t = 0; t < Tp * N_Q; ++t) {
+      const int v = b->prompt_codes[(long)i * b->prompt_stride * N_Q + t];
+      if (v < 0 || v >= AUDIO_VOCAB) FAIL(VX_EINVAL, "row %d: prompt code %d out of range", i, v);
+    }
+  }
+  return VX_OK;
+}
+
+// ---- AR prefill (models/vallex.py:497-562, first ar_decoder.infer call) ------------------------------------
+int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb) {
+  const int NL = c->NL;
+  std::vector<int> seq_off(nb), seq_len(nb), S_(nb), dst_t, id_t, lang_t, pos_t, dst_a, id_a, pos_a, row_b, row_t;
+  long M = 0;
+  int max_len = 0;
+  for (int i = 0; i < nb; ++i) {
+    const int r = r0 + i, S = b->text_lens[r], Tp = b->prompt_lens[r];
+    seq_off[i] = (int)M; seq_len[i] = S + 1 + Tp; S_[i] = S;
+    max_len = std::max(max_len, seq_len[i]);
+    for (int s = 0; s < S; ++s) {
+      dst_t.push_back((int)M + s);
+      id_t.push_back(b->text_ids[(long)r * b->text_stride + s]);
+      lang_t.push_back(b->text_lang[(long)r * b->text_stride + s]);
+      pos_t.push_back(s);
+    }
+    for (int t = 0; t <= Tp; ++t) {                       // BOS then prompt codebook 0 (models/vallex.py:515-517)
+      dst_a.push_back((int)M + S + t);
+      id_a.push_back(t == 0 ? BOS_ID : b->prompt_codes[((long)r * b->prompt_stride + (t - 1)) * N_Q]);
+      pos_a.push_back(t);
+    }
+    for (int t = 0; t < seq_len[i]; ++t) { row_b.push_back(i); row_t.push_back(t); }
+    M += seq_len[i];
+  }
+  if (M > c->Mmax) FAIL(VX_EINVAL, "prefill rows %ld exceed arena %ld", M, c->Mmax);
+  c->h_L = seq_len;
+  MetaBuilder mb(c);
+  const long o_off = mb.add(seq_off), o_len = mb.add(seq_len), o_S = mb.add(S_), o_dt = mb.add(dst_t), o_it = mb.add(id_t),
+             o_lt = mb.add(lang_t), o_pt = mb.add(pos_t), o_da = mb.add(dst_a), o_ia = mb.add(id_a), o_pa = mb.add(pos_a),
+             o_rb = mb.add(row_b), o_rt = mb.add(row_t);
+  // decode state
+  std::vector<int> st_pos(nb), st_ctx(nb), st_zero(nb, 0), st_one(nb, 1), st_S(nb);
+  for (int i = 0; i < nb; ++i) { st_pos[i] = b->prompt_lens[r0 + i]; st_ctx[i] = seq_len[i]; st_S[i] = S_[i]; }
+  const long o_sp = mb.add(st_pos), o_sc = mb.add(st_ctx), o_z = mb.add(st_zero), o_1 = mb.add(st_one), o_sS = mb.add(st_S);
+  if (int e = upload_meta(c)) return e;
+  const size_t ib = nb * sizeof(int);
+  HIPCHK(hipMemcpyAsync(c->cur_pos, mb.dev(o_sp), ib, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->ctx_len, mb.dev(o_sc), ib, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->n_gen, mb.dev(o_z), ib, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->cur_tok, mb.dev(o_z), ib, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->active, mb.dev(o_1), ib, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->text_len, mb.dev(o_sS), ib, hipMemcpyDeviceToDevice, c->stream));
+  c->cur_batch = nb;
+  // enough (row, head, split) blocks to fill 256 CUs a few times over
+  c->nsplit = std::max(1, std::min(16, 1024 / (nb * N_HEAD)));
+
+  launch_embed_rows(c->fx, mb.dev(o_dt), W(c, "ar_text_embedding.word_embeddings.weight"), mb.dev(o_it),
+                    W(c, "ar_language_embedding.word_embeddings.weight"), mb.dev(o_lt), W(c, "ar_text_position.alpha"),
+                    c->pe, mb.dev(o_pt), (int)dst_t.size(), c->stream);
+  launch_embed_rows(c->fx, mb.dev(o_da), W(c, "ar_audio_embedding.word_embeddings.weight"), mb.dev(o_ia), nullptr,
+                    nullptr, W(c, "ar_audio_position.alpha"), c->pe, mb.dev(o_pa), (int)dst_a.size(), c->stream);
+  if (int e = tap_store(c, "ar_prefill_in", c->fx, (size_t)M * D_MODEL)) return e;
+
+  double attn_flops = 0;
+  for (int i = 0; i < nb; ++i) attn_flops += 4.0 * seq_len[i] * (double)seq_len[i] * D_MODEL;
+  const size_t cache_layer = (size_t)c->mbr * N_HEAD * c->Tmax * D_HEAD;
+  for (int l = 0; l < NL; ++l) {
+    if (int e = full_layer(c, c->ar[l], M, mb.dev(o_off), mb.dev(o_len), mb.dev(o_S), nb, max_len, nullptr, nullptr,
+                           c->kc + l * cache_layer, c->vc + l * cache_layer, mb.dev(o_rb), mb.dev(o_rt), attn_flops))
+      return e;
+    if (c->cfg.debug_taps) {
+      char nm[64];
+      snprintf(nm, sizeof nm, "ar_layer_out.%d", l);
+      if (int e = tap_store(c, nm, c->fx, (size_t)M * D_MODEL)) return e;
+    }
+  }
+  // last row of every sequence -> decode residual stream h[b]
+  for (int i = 0; i < nb; ++i)
+    HIPCHK(hipMemcpyAsync(c->dh + (size_t)i * D_MODEL, c->fx + ((size_t)seq_off[i] + seq_len[i] - 1) * D_MODEL,
+                          D_MODEL * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  // final norm + ar_predict_layer on those rows (models/vallex.py:568)
+  launch_dec_reduce_ln_pack(nullptr, 0, D_MODEL, nullptr, c->dh, nullptr, W(c, "ar_decoder.norm.weight"),
+                            W(c, "ar_decoder.norm.bias"), c->xp, nb, c->stream);
+  launch_skinny_gemm(c->pred_wp, c->xp, c->p_logits, PRED_NPAD, D_MODEL, SK_PRED, c->stream);
+  return VX_OK;
+}
+
+SampleArgs make_sample_args(vx_ctx* c, const vx_sampling* s, int commit, float* logits_out) {
+  SampleArgs a{};
+  a.partial = c->p_logits; a.splitk = SK_PRED; a.npad = PRED_NPAD;
+  a.top_k = s ? s->top_k : 1;
+  a.temperature = s ? s->temperature : 1.0f;
+  a.uniforms = (s && s->uniforms) ? c->d_uniforms : nullptr;
+  a.uniforms_stride = c->cur_batch;
+  a.seed = s ? s->seed : 0;
+  a.force_eos_at = s ? s->force_eos_at : -1;
+  a.commit = commit;
+  a.cur_tok = c->cur_tok; a.cur_pos = c->cur_pos; a.ctx_len = c->ctx_len; a.n_gen = c->n_gen; a.active = c->active;
+  a.text_len = c->text_len; a.gen = c->gen; a.gen_stride = c->gen_stride; a.logits_out = logits_out;
+  a.batch = c->cur_batch;
+  return a;
+}
+
+// ---- one cached decode step (models/vallex.py:552-571 with kv_cache set) --------------------------------------
+void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
+  const int nb = c->cur_batch, NL = c->NL;
+  hipStream_t st = c->stream;
+  const size_t cache_layer = (size_t)c->mbr * N_HEAD * c->Tmax * D_HEAD;
+  launch_dec_embed_ln_pack(c->cur_tok, c->cur_pos, W(c, "ar_audio_embedding.word_embeddings.weight"),
+                           W(c, "ar_audio_position.alpha"), c->pe, c->dh, c->ar[0].n1_w, c->ar[0].n1_b, c->xp, nb, st);
+  for (int l = 0; l < NL; ++l) {
+    const LayerW& L = c->ar[l];
+    { ProfScope ps(c, 1); launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, st); }
+    {
+      ProfScope ps(c, 0);
+      launch_dec_attn(c->p_qkv, SK_QKV, L.in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax, c->ctx_len,
+                      c->active, c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, st);
+    }
+    if (c->nsplit > 1) launch_dec_attn_combine(c->part_o, c->part_ml, c->nsplit, c->active, c->xp_att, nb, st);
+    { ProfScope ps(c, 1); launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, st); }
+    launch_dec_reduce_ln_pack(c->p_o, SK_OUT, D_MODEL, L.out_b, c->dh, c->dh, L.n2_w, L.n2_b, c->xp, nb, st);
+    { ProfScope ps(c, 1); launch_skinny_gemm(L.l1_wp, c->xp, c->p_f, D_FF, D_MODEL, SK_L1, st); }
+    launch_dec_reduce_relu_pack(c->p_f, SK_L1, L.l1_b, c->xp4, nb, st);
+    { ProfScope ps(c, 1); launch_skinny_gemm(L.l2_wp, c->xp4, c->p_o, D_MODEL, D_FF, SK_L2, st); }
+    const float* ng = (l + 1 < NL) ? c->ar[l + 1].n1_w : W(c, "ar_decoder.norm.weight");
+    const float* nbp = (l + 1 < NL) ? c->ar[l + 1].n1_b : W(c, "ar_decoder.norm.bias");
+    launch_dec_reduce_ln_pack(c->p_o, SK_L2, D_MODEL, L.l2_b, c->dh, c->dh, ng, nbp, c->xp, nb, st);
+  }
+  { ProfScope ps(c, 1); launch_skinny_gemm(c->pred_wp, c->xp, c->p_logits, PRED_NPAD, D_MODEL, SK_PRED, st); }
+  if (sa) launch_dec_sample(*sa, st);
+}
+
+int ar_step_run(vx_ctx* c, const SampleArgs* sa, const std::string& sig) {
+  if (!c->cfg.use_graph || c->prof_on || !sa) {
+    ar_step_launches(c, sa);
+    HIPCHK(hipGetLastError());
+    return VX_OK;
+  }
+  if (!c->graph_exec || c->graph_sig != sig) {
+    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    ar_step_launches(c, sa);
+    HIPCHK(hipStreamEndCapture(c->stream, &g));
+    HIPCHK(hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    c->graph_sig = sig;
+  }
+  HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
+  return VX_OK;
+}
+
+// ---- AR generation for one micro-batch -----------------------------------------------------------------------
+int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int nb, std::vector<int>& n_gen,
+                std::vector<int>& gen) {
+  if (int e = ar_prefill(c, b, r0, nb)) return e;
+  if (s->uniforms) {
+    // slice [steps][batch] -> [steps][nb] for this micro-batch
+    const long steps = s->uniforms_steps;
+    if (steps * nb > c->uniforms_cap) FAIL(VX_EINVAL, "too many uniforms (%ld steps)", steps);
+    std::vector<float> u((size_t)steps * nb);
+    for (long t = 0; t < steps; ++t)
+      for (int i = 0; i < nb; ++i) u[t * nb + i] = s->uniforms[t * b->batch + r0 + i];
+    HIPCHK(hipMemcpyAsync(c->d_uniforms, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  SampleArgs sa = make_sample_args(c, s, 1, nullptr);
+  launch_dec_sample(sa, c->stream);                                     // first token from the prefill logits
+  char sig[160];
+  snprintf(sig, sizeof sig, "b%d ns%d k%d t%a u%d f%d s%llu", nb, c->nsplit, sa.top_k, sa.temperature,
+           sa.uniforms != nullptr, sa.force_eos_at, (unsigned long long)sa.seed);
+  const int sync_every = s->sync_every > 0 ? s->sync_every : 8;
+  std::vector<int> act(nb);
+  const int hard_cap = c->gen_stride + 2;
+  int steps = 0;
+  bool any = true;
+  // was anything left active after the first sample?
+  HIPCHK(hipMemcpyAsync(act.data(), c->active, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  any = std::any_of(act.begin(), act.end(), [](int v) { return v != 0; });
+  while (any && steps < hard_cap) {
+    if (int e = ar_step_run(c, &sa, sig)) return e;
+    ++steps;
+    if (steps % sync_every == 0) {
+      HIPCHK(hipMemcpyAsync(act.data(), c->active, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      any = std::any_of(act.begin(), act.end(), [](int v) { return v != 0; });
+    }
+  }
+  n_gen.resize(nb);
+  gen.resize((size_t)nb * c->gen_stride);
+  HIPCHK(hipMemcpyAsync(n_gen.data(), c->n_gen, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(gen.data(), c->gen, gen.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->st_steps += steps;
+  if (c->prof_on) {
+    // algorithmic KV bytes: every decode step of an active row reads ctx rows of K and V in all layers
+    for (int i = 0; i < nb; ++i)
+      for (int t = 1; t <= n_gen[i]; ++t)
+        c->prof[0].bytes += (double)c->NL * ((double)(c->h_L[i] + t) * 2.0 * D_MODEL * 4.0);
+    c->prof[1].bytes += (double)steps * ((double)c->NL * 12.0 * D_MODEL * D_MODEL + (double)AR_LOGITS * D_MODEL) * 4.0;
+  }
+  return VX_OK;
+}
+
+// ---- NAR: 7 stages (models/vallex.py:600-686, prefix_mode 1) ----------------------------------------------------
+int nar_generate(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::vector<int>& T, const int* codes0,
+                 long codes0_stride, std::vector<int>& out_codes /* [7][sumT] */, long& sumT_out) {
+  const int NL = c->NL;
+  std::vector<int> seq_off(nb), seq_len(nb), dst_t, id_t, lang_t, pos_t, ycodes, ynj, ydst, ypos, gen_rows, gen_y;
+  long M = 0, Y = 0, sumT = 0;
+  int max_len = 0;
+  for (int i = 0; i < nb; ++i) {
+    const int r = r0 + i, S = b->text_lens[r], Tp = b->prompt_lens[r];
+    seq_off[i] = (int)M; seq_len[i] = S + Tp + T[i];
+    max_len = std::max(max_len, seq_len[i]);
+    for (int s = 0; s < S; ++s) {
+      dst_t.push_back((int)M + s);
+      id_t.push_back(b->text_ids[(long)r * b->text_stride + s]);
+      lang_t.push_back(b->text_lang[(long)r * b->text_stride + s]);
+      pos_t.push_back(s);
+    }
+    for (int t = 0; t < Tp + T[i]; ++t) {
+      if (t < Tp) {
+        for (int j = 0; j < N_Q; ++j) ycodes.push_back(b->prompt_codes[((long)r * b->prompt_stride + t) * N_Q + j]);
+        ynj.push_back(N_Q);
+      } else {
+        ycodes.push_back(codes0[(long)i * codes0_stride + (t - Tp)]);
+        for (int j = 1; j < N_Q; ++j) ycodes.push_back(0);
+        ynj.push_back(1);
+        gen_rows.push_back((int)M + S + t);
+        gen_y.push_back((int)Y + t);
+      }
+      ydst.push_back((int)M + S + t);
+      ypos.push_back(t);
+    }
+    M += seq_len[i]; Y += Tp + T[i]; sumT += T[i];
+  }
+  sumT_out = sumT;
+  out_codes.assign((size_t)(N_Q - 1) * sumT, 0);
+  if (sumT == 0) return VX_OK;
+  if (M > c->Mmax) FAIL(VX_EINVAL, "NAR rows %ld exceed arena %ld", M, c->Mmax);
+  MetaBuilder mb(c);
+  const long o_off = mb.add(seq_off), o_len = mb.add(seq_len), o_dt = mb.add(dst_t), o_it = mb.add(id_t),
+             o_lt = mb.add(lang_t), o_pt = mb.add(pos_t), o_yc = mb.add(ycodes), o_nj = mb.add(ynj), o_yd = mb.add(ydst),
+             o_yp = mb.add(ypos), o_gr = mb.add(gen_rows), o_gy = mb.add(gen_y);
+  std::vector<int> zeros((size_t)(N_Q - 1) * sumT, 0);
+  const long o_samples = mb.add(zeros);
+  if (int e = upload_meta(c)) return e;
+
+  launch_nar_yemb_init(c->fyemb, c->nar_tabs_dev, mb.dev(o_yc), mb.dev(o_nj), (int)Y, c->stream);
+  double attn_flops = 0;
+  for (int i = 0; i < nb; ++i) attn_flops += 4.0 * seq_len[i] * (double)seq_len[i] * D_MODEL;
+  const int nnorm = 2 * NL + 1;
+  for (int st = 0; st < N_Q - 1; ++st) {
+    launch_embed_rows(c->fx, mb.dev(o_dt), W(c, "nar_text_embedding.word_embeddings.weight"), mb.dev(o_it),
+                      W(c, "nar_language_embedding.word_embeddings.weight"), mb.dev(o_lt),
+                      W(c, "nar_text_position.alpha"), c->pe, mb.dev(o_pt), (int)dst_t.size(), c->stream);
+    launch_add_pe_scatter(c->fx, mb.dev(o_yd), c->fyemb, W(c, "nar_audio_position.alpha"), c->pe, mb.dev(o_yp), (int)Y,
+                          c->stream);
+    const float* ada = c->ada + (size_t)st * nnorm * 2 * D_MODEL;
+    for (int l = 0; l < NL; ++l) {
+      if (int e = full_layer(c, c->nar[l], M, mb.dev(o_off), mb.dev(o_len), nullptr, nb, max_len,
+                             ada + (size_t)(2 * l) * 2 * D_MODEL, ada + (size_t)(2 * l + 1) * 2 * D_MODEL, nullptr, nullptr,
+                             nullptr, nullptr, attn_flops))
+        return e;
+      if (c->cfg.debug_taps && st == 0) {
+        char nm[64];
+        snprintf(nm, sizeof nm, "nar_layer_out.%d", l);
+        if (int e = tap_store(c, nm, c->fx, (size_t)M * D_MODEL)) return e;
+      }
+    }
+    const float* adaf = ada + (size_t)(2 * NL) * 2 * D_MODEL;
+    launch_layernorm(c->fx, D_MODEL, c->fxn, D_MODEL, (int)M, D_MODEL, LN_EPS, W(c, "nar_decoder.norm.norm.weight"),
+                     W(c, "nar_decoder.norm.norm.bias"), adaf, adaf + D_MODEL, c->stream);
+    char nm[64];
+    snprintf(nm, sizeof nm, "nar_predict_layers.%d.weight", st);
+    gemm(c, c->fxn, D_MODEL, W(c, nm), D_MODEL, nullptr, nullptr, 0, nullptr, c->flogits, AUDIO_VOCAB, sumT, AUDIO_VOCAB,
+         D_MODEL, ACT_NONE, mb.dev(o_gr));
+    if (c->cfg.debug_taps && st == 0)
+      if (int e = tap_store(c, "nar_logits0", c->flogits, (size_t)sumT * AUDIO_VOCAB)) return e;
+    int* samples = c->imeta + o_samples + (long)st * sumT;
+    launch_argmax_rows(c->flogits, AUDIO_VOCAB, (int)sumT, AUDIO_VOCAB, samples, c->stream);
+    if (st < N_Q - 2) {
+      snprintf(nm, sizeof nm, "nar_audio_embeddings.%d.word_embeddings.weight", st + 1);
+      launch_embed_accum(c->fyemb, mb.dev(o_gy), W(c, nm), samples, (int)sumT, c->stream);
+    }
+  }
+  HIPCHK(hipMemcpyAsync(out_codes.data(), c->imeta + o_samples, out_codes.size() * sizeof(int), hipMemcpyDeviceToHost,
+                        c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return VX_OK;
+}
+
+int need(vx_ctx* c, const std::string& name, std::initializer_list<int64_t> shape) {
+  auto it = c->w.find(name);
+  if (it == c->w.end()) FAIL(VX_ENOTFOUND, "missing tensor '%s'", name.c_str());
+  if (it->second.shape != std::vector<int64_t>(shape)) FAIL(VX_EINVAL, "tensor '%s' has the wrong shape", name.c_str());
+  return VX_OK;
+}
+
+int pack(vx_ctx* c, const float* Wt, int N, int K, int Npad, float** out) {
+  if (int e = dev_alloc(c, out, (size_t)Npad * K, false)) return e;
+  launch_pack_weight(Wt, N, K, *out, Npad, c->stream);
+  return VX_OK;
+}
+
+}  // namespace
+
+// =================================================================================================================
+// C ABI
+// =================================================================================================================
+extern "C" {
+
+const char* vx_last_error(const vx_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int vx_create(int device_id, const vx_config* cfg, vx_ctx** out) {
+  if (!cfg || !out) { g_create_err = "null argument"; return VX_EINVAL; }
+  if (cfg->num_layers <= 0 || cfg->max_batch <= 0 || cfg->max_text <= 0 || cfg->max_prompt < 0 || cfg->max_new <= 0) {
+    g_create_err = "invalid vx_config";
+    return VX_EINVAL;
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_err = std::string("no HIP device available: ") + hipGetErrorString(e);
+    return VX_EHIP;
+  }
+  if (device_id < 0 || device_id >= ndev) { g_create_err = "device_id out of range"; return VX_EINVAL; }
+  vx_ctx* c = new vx_ctx();
+  c->cfg = *cfg;
+  c->dev = device_id;
+  c->NL = cfg->num_layers;
+  auto fail = [&](hipError_t err, const char* what) {
+    g_create_err = std::string(what) + ": " + hipGetErrorString(err);
+    delete c;
+    return VX_EHIP;
+  };
+  if ((e = hipSetDevice(device_id)) != hipSuccess) return fail(e, "hipSetDevice");
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+  *out = c;
+  return VX_OK;
+}
+
+void vx_destroy(vx_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->dev);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+  for (auto& p : c->prof) for (auto ev : p.ev) (void)hipEventDestroy(ev);
+  for (void* p : c->allocs) (void)hipFree(p);
+  for (auto& kv : c->w) (void)hipFree(kv.second.d);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int vx_synchronize(vx_ctx* c) {
+  if (!c) return VX_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return VX_OK;
+}
+
+int vx_load_tensor(vx_ctx* c, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
+  if (!c) return VX_EINVAL;
+  if (!name || !data || !shape || ndim < 0 || ndim > 4) FAIL(VX_EINVAL, "bad tensor argument");
+  if (c->finalized) FAIL(VX_ESTATE, "weights already finalized");
+  HIPCHK(hipSetDevice(c->dev));
+  Tensor t;
+  t.n = 1;
+  for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); t.n *= (size_t)shape[i]; }
+  auto it = c->w.find(name);
+  if (it != c->w.end()) { (void)hipFree(it->second.d); c->w.erase(it); }
+  void* q = nullptr;
+  HIPCHK(hipMalloc(&q, std::max<size_t>(t.n, 1) * sizeof(float)));
+  t.d = reinterpret_cast<float*>(q);
+  HIPCHK(hipMemcpy(t.d, data, t.n * sizeof(float), hipMemcpyHostToDevice));
+  c->w[name] = t;
+  return VX_OK;
+}
+
+int vx_finalize_weights(vx_ctx* c) {
+  if (!c) return VX_EINVAL;
+  if (c->finalized) return VX_OK;
+  HIPCHK(hipSetDevice(c->dev));
+  const int NL = c->NL, d = D_MODEL, f = D_FF;
+  // ---- presence + shape of the reference state-dict ----
+  int e;
+#define NEED(...) if ((e = need(c, __VA_ARGS__))) return e
+  NEED("ar_text_embedding.word_embeddings.weight", {2048, d});
+  NEED("nar_text_embedding.word_embeddings.weight", {2048, d});
+  NEED("ar_audio_embedding.word_embeddings.weight", {AUDIO_VOCAB + 2, d});
+  NEED("ar_language_embedding.word_embeddings.weight", {3, d});
+  NEED("nar_language_embedding.word_embeddings.weight", {3, d});
+  for (const char* a : {"ar_text_position.alpha", "ar_audio_position.alpha", "nar_text_position.alpha",
+                        "nar_audio_position.alpha"})
+    NEED(a, {1});
+  NEED("ar_decoder.norm.weight", {d});
+  NEED("ar_decoder.norm.bias", {d});
+  NEED("ar_predict_layer.weight", {AR_LOGITS, d});
+  NEED("nar_audio_embeddings.0.word_embeddings.weight", {AUDIO_VOCAB + 1, d});
+  for (int j = 1; j < N_Q; ++j) NEED("nar_audio_embeddings." + std::to_string(j) + ".word_embeddings.weight", {AUDIO_VOCAB, d});
+  for (int j = 0; j < N_Q - 1; ++j) {
+    NEED("nar_predict_layers." + std::to_string(j) + ".weight", {AUDIO_VOCAB, d});
+    NEED("nar_stage_embeddings." + std::to_string(j) + ".word_embeddings.weight", {1, d});
+  }
+  NEED("nar_decoder.norm.project_layer.weight", {2 * d, d});
+  NEED("nar_decoder.norm.project_layer.bias", {2 * d});
+  NEED("nar_decoder.norm.norm.weight", {d});
+  NEED("nar_decoder.norm.norm.bias", {d});
+  c->ar.resize(NL);
+  c->nar.resize(NL);
+  for (int which = 0; which < 2; ++which)
+    for (int l = 0; l < NL; ++l) {
+      const std::string p = std::string(which ? "nar" : "ar") + "_decoder.layers." + std::to_string(l) + ".";
+      NEED(p + "self_attn.in_proj_weight", {3 * d, d});
+      NEED(p + "self_attn.in_proj_bias", {3 * d});
+      NEED(p + "self_attn.out_proj.weight", {d, d});
+      NEED(p + "self_attn.out_proj.bias", {d});
+      NEED(p + "linear1.weight", {f, d});
+      NEED(p + "linear1.bias", {f});
+      NEED(p + "linear2.weight", {d, f});
+      NEED(p + "linear2.bias", {d});
+      const std::string n1 = which ? p + "norm1.norm." : p + "norm1.", n2 = which ? p + "norm2.norm." : p + "norm2.";
+      NEED(n1 + "weight", {d});
+      NEED(n1 + "bias", {d});
+      NEED(n2 + "weight", {d});
+      NEED(n2 + "bias", {d});
+      if (which) {
+        NEED(p + "norm1.project_layer.weight", {2 * d, d});
+        NEED(p + "norm1.project_layer.bias", {2 * d});
+        NEED(p + "norm2.project_layer.weight", {2 * d, d});
+        NEED(p + "norm2.project_layer.bias", {2 * d});
+      }
+      LayerW& L = which ? c->nar[l] : c->ar[l];
+      L.in_w = W(c, p + "self_attn.in_proj_weight"); L.in_b = W(c, p + "self_attn.in_proj_bias");
+      L.out_w = W(c, p + "self_attn.out_proj.weight"); L.out_b = W(c, p + "self_attn.out_proj.bias");
+      L.l1_w = W(c, p + "linear1.weight"); L.l1_b = W(c, p + "linear1.bias");
+      L.l2_w = W(c, p + "linear2.weight"); L.l2_b = W(c, p + "linear2.bias");
+      L.n1_w = W(c, n1 + "weight"); L.n1_b = W(c, n1 + "bias");
+      L.n2_w = W(c, n2 + "weight"); L.n2_b = W(c, n2 + "bias");
+    }
+#undef NEED
+
+  // ---- geometry + arenas ----
+  c->mbr = std::min(c->cfg.max_batch, MB);
+  c->Tmax = c->cfg.max_text + 1 + c->cfg.max_prompt + c->cfg.max_new + 1;
+  c->Mmax = (long)c->mbr * (c->cfg.max_text + c->cfg.max_prompt + c->cfg.max_new + 1);
+  c->gen_stride = c->cfg.max_new;
+  const long M = c->Mmax + 128;
+  if ((e = dev_alloc(c, &c->fx, (size_t)M * d))) return e;
+  if ((e = dev_alloc(c, &c->fxn, (size_t)M * d))) return e;
+  if ((e = dev_alloc(c, &c->fqkv, (size_t)M * 3 * d))) return e;
+  if ((e = dev_alloc(c, &c->fatt, (size_t)M * d))) return e;
+  if ((e = dev_alloc(c, &c->fffn, (size_t)M * f))) return e;
+  if ((e = dev_alloc(c, &c->fyemb, (size_t)M * d))) return e;
+  if ((e = dev_alloc(c, &c->flogits, (size_t)((long)c->mbr * c->cfg.max_new + 128) * AUDIO_VOCAB))) return e;
+  c->imeta_cap = std::max(M * 24, (long)c->cfg.max_batch * c->cfg.max_new * 12) + 65536;
+  if ((e = dev_alloc(c, &c->imeta, (size_t)c->imeta_cap))) return e;
+  const size_t cache = (size_t)NL * c->mbr * N_HEAD * c->Tmax * D_HEAD;
+  if ((e = dev_alloc(c, &c->kc, cache, false))) return e;
+  if ((e = dev_alloc(c, &c->vc, cache, false))) return e;
+  if ((e = dev_alloc(c, &c->dh, (size_t)MB * d))) return e;
+  if ((e = dev_alloc(c, &c->xp, (size_t)MB * d))) return e;
+  if ((e = dev_alloc(c, &c->xp_att, (size_t)MB * d))) return e;
+  if ((e = dev_alloc(c, &c->xp4, (size_t)MB * f))) return e;
+  if ((e = dev_alloc(c, &c->p_qkv, (size_t)SK_QKV * MB * 3 * d))) return e;
+  if ((e = dev_alloc(c, &c->p_o, (size_t)std::max(SK_OUT, SK_L2) * MB * d))) return e;
+  if ((e = dev_alloc(c, &c->p_f, (size_t)SK_L1 * MB * f))) return e;
+  if ((e = dev_alloc(c, &c->p_logits, (size_t)SK_PRED * MB * PRED_NPAD))) return e;
+  if ((e = dev_alloc(c, &c->part_o, (size_t)MB * N_HEAD * 16 * D_HEAD))) return e;
+  if ((e = dev_alloc(c, &c->part_ml, (size_t)MB * N_HEAD * 16 * 2))) return e;
+  if ((e = dev_alloc(c, &c->d_logits, (size_t)MB * AR_LOGITS))) return e;
+  c->uniforms_cap = (long)(c->cfg.max_new + 2) * MB;
+  if ((e = dev_alloc(c, &c->d_uniforms, (size_t)c->uniforms_cap))) return e;
+  for (int** p : {&c->cur_tok, &c->cur_pos, &c->ctx_len, &c->n_gen, &c->active, &c->text_len, &c->force_tok})
+    if ((e = dev_alloc(c, p, MB))) return e;
+  if ((e = dev_alloc(c, &c->gen, (size_t)MB * c->gen_stride))) return e;
+
+  // ---- positional table, built on the host exactly like modules/embedding.py:75-91 (fp32 ops in the same order) ----
+  {
+    c->pe_rows = std::max(4000, c->Tmax + 8);
+    std::vector<float> pe((size_t)c->pe_rows * d);
+    std::vector<float> div(d / 2);
+    const float k = -(float)(log(10000.0) / d);            // python float math.log(10000.0)/d, then cast in the product
+    for (int i = 0; i < d / 2; ++i) div[i] = expf((float)(2 * i) * k);
+    for (int p = 0; p < c->pe_rows; ++p)
+      for (int i = 0; i < d / 2; ++i) {
+        const float a = (float)p * div[i];
+        pe[(size_t)p * d + 2 * i] = sinf(a);
+        pe[(size_t)p * d + 2 * i + 1] = cosf(a);
+      }
+    if ((e = dev_alloc(c, &c->pe, pe.size(), false))) return e;
+    HIPCHK(hipMemcpy(c->pe, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  // a caller-supplied table (built with torch on the host) overrides ours bit for bit
+  if (const float* user_pe = W(c, "pe_table")) {
+    const Tensor& t = c->w["pe_table"];
+    if (t.shape.size() == 2 && t.shape[1] == d && t.shape[0] >= c->Tmax) { c->pe = const_cast<float*>(user_pe); c->pe_rows = (int)t.shape[0]; }
+  }
+
+  // ---- packed decode images of the AR stack ----
+  for (int l = 0; l < NL; ++l) {
+    LayerW& L = c->ar[l];
+    if ((e = pack(c, L.in_w, 3 * d, d, 3 * d, &L.in_wp))) return e;
+    if ((e = pack(c, L.out_w, d, d, d, &L.out_wp))) return e;
+    if ((e = pack(c, L.l1_w, f, d, f, &L.l1_wp))) return e;
+    if ((e = pack(c, L.l2_w, d, f, d, &L.l2_wp))) return e;
+  }
+  if ((e = pack(c, W(c, "ar_predict_layer.weight"), AR_LOGITS, d, PRED_NPAD, &c->pred_wp))) return e;
+
+  // ---- AdaLN projections of the 7 stage embeddings (modules/transformer.py:96-100), input independent ----
+  {
+    const int nnorm = 2 * NL + 1;
+    if ((e = dev_alloc(c, &c->ada, (size_t)(N_Q - 1) * nnorm * 2 * d, false))) return e;
+    for (int st = 0; st < N_Q - 1; ++st) {
+      const float* emb = W(c, "nar_stage_embeddings." + std::to_string(st) + ".word_embeddings.weight");
+      for (int n = 0; n < nnorm; ++n) {
+        std::string p;
+        if (n == 2 * NL) p = "nar_decoder.norm.project_layer.";
+        else p = "nar_decoder.layers." + std::to_string(n / 2) + (n % 2 ? ".norm2" : ".norm1") + ".project_layer.";
+        launch_gemv(W(c, p + "weight"), emb, W(c, p + "bias"), c->ada + ((size_t)st * nnorm + n) * 2 * d, 2 * d, d,
+                    c->stream);
+      }
+    }
+  }
+  {
+    std::vector<const float*> tabs(N_Q);
+    for (int j = 0; j < N_Q; ++j) tabs[j] = W(c, "nar_audio_embeddings." + std::to_string(j) + ".word_embeddings.weight");
+    float** tmp = nullptr;
+    if ((e = dev_alloc(c, &tmp, N_Q, false))) return e;
+    HIPCHK(hipMemcpy((void*)tmp, tabs.data(), N_Q * sizeof(float*), hipMemcpyHostToDevice));
+    c->nar_tabs_dev = const_cast<const float**>(tmp);
+  }
+
+  // ---- Vocos head (optional) ----
+  if (c->cfg.with_vocos && c->w.count("vocos.head.out.weight")) {
+    const int C = 384, H = 1152, NB = 1282, NBP = 1408, KP = 1312, NF = 1280;
+#define NEED(...) if ((e = need(c, __VA_ARGS__))) return e
+    NEED("vocos.feature_extractor.codebook_weights", {16384, 128});
+    NEED("vocos.backbone.embed.weight", {C, 128, 7});
+    NEED("vocos.backbone.embed.bias", {C});
+    NEED("vocos.backbone.norm.scale.weight", {4, C});
+    NEED("vocos.backbone.norm.shift.weight", {4, C});
+    for (int i = 0; i < 8; ++i) {
+      const std::string p = "vocos.backbone.convnext." + std::to_string(i) + ".";
+      NEED(p + "dwconv.weight", {C, 1, 7});
+      NEED(p + "dwconv.bias", {C});
+      NEED(p + "norm.scale.weight", {4, C});
+      NEED(p + "norm.shift.weight", {4, C});
+      NEED(p + "pwconv1.weight", {H, C});
+      NEED(p + "pwconv1.bias", {H});
+      NEED(p + "pwconv2.weight", {C, H});
+      NEED(p + "pwconv2.bias", {C});
+      NEED(p + "gamma", {C});
+    }
+    NEED("vocos.backbone.final_layer_norm.weight", {C});
+    NEED("vocos.backbone.final_layer_norm.bias", {C});
+    NEED("vocos.head.out.weight", {NB, C});
+    NEED("vocos.head.out.bias", {NB});
+#undef NEED
+    // embed conv weight (384,128,7) -> [384][tap*128 + c] to match the im2col rows
+    {
+      std::vector<float> w((size_t)C * 128 * 7), w2((size_t)C * 896);
+      HIPCHK(hipMemcpy(w.data(), W(c, "vocos.backbone.embed.weight"), w.size() * sizeof(float), hipMemcpyDeviceToHost));
+      for (int o = 0; o < C; ++o)
+        for (int ch = 0; ch < 128; ++ch)
+          for (int tap = 0; tap < 7; ++tap) w2[(size_t)o * 896 + tap * 128 + ch] = w[((size_t)o * 128 + ch) * 7 + tap];
+      if ((e = dev_alloc(c, &c->vc_embed_w, w2.size(), false))) return e;
+      HIPCHK(hipMemcpy(c->vc_embed_w, w2.data(), w2.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    // head weight/bias padded 1282 -> 1408 rows (GEMM N multiple of 128)
+    if ((e = dev_alloc(c, &c->vc_head_w, (size_t)NBP * C))) return e;
+    if ((e = dev_alloc(c, &c->vc_head_b, NBP))) return e;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(c->vc_head_w, W(c, "vocos.head.out.weight"), (size_t)NB * C * sizeof(float), hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(c->vc_head_b, W(c, "vocos.head.out.bias"), (size_t)NB * sizeof(float), hipMemcpyDeviceToDevice));
+    // inverse real DFT (irfft n=1280, norm="backward") with the hann window folded in, as a [1280][1312] matrix:
+    // frame[n] = win[n]/N * ( re0 + (-1)^n re_{N/2} + 2 sum_{k=1}^{N/2-1} re_k cos(2 pi k n/N) - im_k sin(2 pi k n/N) )
+    {
+      std::vector<float> dft((size_t)NF * KP, 0.f), win2(NF);
+      const double PI = 3.14159265358979323846;
+      for (int n = 0; n < NF; ++n) {
+        const double wn = 0.5 - 0.5 * cos(2.0 * PI * n / NF);             // torch.hann_window(periodic=True)
+        win2[n] = (float)((double)(float)wn * (double)(float)wn);
+        const double sc = (double)(float)wn / NF;
+        float* row = &dft[(size_t)n * KP];
+        row[0] = (float)sc;
+        row[640] = (float)(sc * ((n & 1) ? -1.0 : 1.0));
+        for (int k = 1; k < 640; ++k) {
+          const double ang = 2.0 * PI * (double)((long)k * n % NF) / NF;
+          row[k] = (float)(2.0 * sc * cos(ang));
+          row[641 + k] = (float)(-2.0 * sc * sin(ang));
+        }
+      }
+      if ((e = dev_alloc(c, &c->vc_dft, dft.size(), false))) return e;
+      if ((e = dev_alloc(c, &c->vc_win2, win2.size(), false))) return e;
+      HIPCHK(hipMemcpy(c->vc_dft, dft.data(), dft.size() * sizeof(float), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(c->vc_win2, win2.data(), win2.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    c->v_rows_cap = (long)c->cfg.max_batch * c->cfg.max_new;
+    const long R = c->v_rows_cap + 128;
+    if ((e = dev_alloc(c, &c->vfeat, (size_t)R * 128))) return e;
+    if ((e = dev_alloc(c, &c->vcol, (size_t)R * 896))) return e;
+    if ((e = dev_alloc(c, &c->vx0, (size_t)R * C))) return e;
+    if ((e = dev_alloc(c, &c->vx1, (size_t)R * C))) return e;
+    if ((e = dev_alloc(c, &c->vhid, (size_t)R * H))) return e;
+    if ((e = dev_alloc(c, &c->vo, (size_t)R * NBP))) return e;
+    if ((e = dev_alloc(c, &c->vreim, (size_t)R * KP))) return e;
+    if ((e = dev_alloc(c, &c->vframes, (size_t)R * NF))) return e;
+    if ((e = dev_alloc(c, &c->vaudio, (size_t)c->cfg.max_batch * c->cfg.max_new * 320))) return e;
+    c->has_vocos = true;
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipGetLastError());
+  c->finalized = true;
+  return VX_OK;
+}
+
+int vx_ar_prefill(vx_ctx* c, const vx_batch* b) {
+  if (!c) return VX_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  if (int e = check_batch(c, b, c->mbr)) return e;
+  if (int e = ar_prefill(c, b, 0, b->batch)) return e;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipGetLastError());
+  return VX_OK;
+}
+
+int vx_ar_logits(vx_ctx* c, float* out) {
+  if (!c || !out) return VX_EINVAL;
+  if (c->cur_batch <= 0) FAIL(VX_ESTATE, "no prefill has run");
+  HIPCHK(hipSetDevice(c->dev));
+  SampleArgs sa = make_sample_args(c, nullptr, 0, c->d_logits);
+  launch_dec_sample(sa, c->stream);
+  HIPCHK(hipMemcpyAsync(out, c->d_logits, (size_t)c->cur_batch * AR_LOGITS * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return VX_OK;
+}
+
+int vx_ar_step(vx_ctx* c, const int32_t* tokens) {
+  if (!c || !tokens) return VX_EINVAL;
+  if (c->cur_batch <= 0) FAIL(VX_ESTATE, "no prefill has run");
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipMemcpyAsync(c->force_tok, tokens, c->cur_batch * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  launch_dec_force_token(c->force_tok, c->cur_tok, c->cur_pos, c->ctx_len, c->n_gen, c->gen, c->gen_stride, c->active,
+                         c->cur_batch, c->stream);
+  if (int e = ar_step_run(c, nullptr, "")) return e;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipGetLastError());
+  return VX_OK;
+}
+
+int vx_nar(vx_ctx* c, const vx_batch* b, const int32_t* codes0, int32_t codes0_stride, const int32_t* lens,
+           int64_t* out_codes, int32_t out_stride) {
+  if (!c || !codes0 || !lens || !out_codes) return VX_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  if (int e = check_batch(c, b, c->mbr)) return e;
+  std::vector<int> T(lens, lens + b->batch);
+  for (int i = 0; i < b->batch; ++i)
+    if (T[i] < 0 || T[i] > c->cfg.max_new || T[i] > out_stride) FAIL(VX_EINVAL, "row %d: bad length %d", i, T[i]);
+  std::vector<int> oc;
+  long sumT = 0;
+  if (int e = nar_generate(c, b, 0, b->batch, T, codes0, codes0_stride, oc, sumT)) return e;
+  long off = 0;
+  for (int i = 0; i < b->batch; ++i) {
+    for (int t = 0; t < T[i]; ++t) {
+      int64_t* o = out_codes + ((long)i * out_stride + t) * N_Q;
+      o[0] = codes0[(long)i * codes0_stride + t];
+      for (int st = 0; st < N_Q - 1; ++st) o[st + 1] = oc[(size_t)st * sumT + off + t];
+    }
+    off += T[i];
+  }
+  return VX_OK;
+}
+
+int vx_infer(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int64_t* out_codes, int32_t out_stride,
+             int32_t* out_lens) {
+  if (!c || !s || !out_codes || !out_lens) return VX_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  if (int e = check_batch(c, b, c->cfg.max_batch)) return e;
+  if (!(s->temperature > 0.f)) FAIL(VX_EINVAL, "temperature must be > 0");
+  c->st_steps = 0; c->st_frames = 0; c->st_ar_ms = 0; c->st_nar_ms = 0;
+  hipEvent_t e0, e1, e2;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
+  for (int r0 = 0; r0 < b->batch; r0 += c->mbr) {
+    const int nb = std::min(c->mbr, b->batch - r0);
+    std::vector<int> n_gen, gen, oc;
+    HIPCHK(hipEventRecord(e0, c->stream));
+    if (int e = ar_generate(c, b, s, r0, nb, n_gen, gen)) return e;
+    HIPCHK(hipEventRecord(e1, c->stream));
+    for (int i = 0; i < nb; ++i)
+      if (n_gen[i] > out_stride) FAIL(VX_EINVAL, "out_stride %d too small for %d frames", out_stride, n_gen[i]);
+    long sumT = 0;
+    if (int e = nar_generate(c, b, r0, nb, n_gen, gen.data(), c->gen_stride, oc, sumT)) return e;
+    HIPCHK(hipEventRecord(e2, c->stream));
+    HIPCHK(hipEventSynchronize(e2));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1)); c->st_ar_ms += ms;
+    HIPCHK(hipEventElapsedTime(&ms, e1, e2)); c->st_nar_ms += ms;
+    long off = 0;
+    for (int i = 0; i < nb; ++i) {
+      out_lens[r0 + i] = n_gen[i];
+      c->st_frames += n_gen[i];
+      for (int t = 0; t < n_gen[i]; ++t) {
+        int64_t* o = out_codes + ((long)(r0 + i) * out_stride + t) * N_Q;
+        o[0] = gen[(size_t)i * c->gen_stride + t];
+        for (int st = 0; st < N_Q - 1; ++st) o[st + 1] = oc[(size_t)st * sumT + off + t];
+      }
+      off += n_gen[i];
+    }
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+  return VX_OK;
+}
+
+int vx_vocos_decode(vx_ctx* c, const int64_t* codes, int32_t codes_stride, const int32_t* lens, int32_t batch,
+                    int32_t bandwidth_id, float* audio, int64_t audio_stride) {
+  if (!c || !codes || !lens || !audio) return VX_EINVAL;
+  if (!c->finalized || !c->has_vocos) FAIL(VX_ESTATE, "Vocos weights not loaded");
+  if (batch <= 0 || batch > c->cfg.max_batch) FAIL(VX_EINVAL, "bad batch");
+  if (bandwidth_id < 0 || bandwidth_id > 3) FAIL(VX_EINVAL, "bandwidth_id must be 0..3");
+  HIPCHK(hipSetDevice(c->dev));
+  const int C = 384, H = 1152, NBP = 1408, KP = 1312, NF = 1280;
+  std::vector<int> seq_off(batch), seq_len(batch), row_t, row_len, cd;
+  long R = 0;
+  int maxT = 0;
+  for (int i = 0; i < batch; ++i) {
+    const int T = lens[i];
+    if (T < 0 || T > c->cfg.max_new || T > codes_stride) FAIL(VX_EINVAL, "row %d: bad length", i);
+    if ((long)T * 320 > audio_stride) FAIL(VX_EINVAL, "audio_stride too small");
+    seq_off[i] = (int)R; seq_len[i] = T; maxT = std::max(maxT, T);
+    for (int t = 0; t < T; ++t) {
+      row_t.push_back(t); row_len.push_back(T);
+      for (int q = 0; q < N_Q; ++q) {
+        const int64_t v = codes[((long)i * codes_stride + t) * N_Q + q];
+        if (v < 0 || v >= AUDIO_VOCAB) FAIL(VX_EINVAL, "code out of range");
+        cd.push_back((int)v);
+      }
+    }
+    R += T;
+  }
+  if (R == 0) return VX_OK;
+  if (R > c->v_rows_cap) FAIL(VX_EINVAL, "too many frames");
+  MetaBuilder mb(c);
+  const long o_off = mb.add(seq_off), o_len = mb.add(seq_len), o_rt = mb.add(row_t), o_rl = mb.add(row_len), o_cd = mb.add(cd);
+  if (int e = upload_meta(c)) return e;
+  hipStream_t st = c->stream;
+  const std::string P = "vocos.backbone.";
+  launch_codebook_sum(mb.dev(o_cd), W(c, "vocos.feature_extractor.codebook_weights"), c->vfeat, (int)R, st);
+  launch_im2col7(c->vfeat, 128, mb.dev(o_rt), mb.dev(o_rl), c->vcol, (int)R, st);
+  gemm(c, c->vcol, 896, c->vc_embed_w, 896, W(c, P + "embed.bias"), nullptr, 0, nullptr, c->vx0, C, R, C, 896, ACT_NONE);
+  launch_layernorm(c->vx0, C, c->vx0, C, (int)R, C, 1e-6f, nullptr, nullptr, W(c, P + "norm.scale.weight") + bandwidth_id * C,
+                   W(c, P + "norm.shift.weight") + bandwidth_id * C, st);
+  for (int i = 0; i < 8; ++i) {
+    const std::string p = P + "convnext." + std::to_string(i) + ".";
+    launch_dwconv7(c->vx0, W(c, p + "dwconv.weight"), W(c, p + "dwconv.bias"), mb.dev(o_rt), mb.dev(o_rl), c->vx1, (int)R, C, st);
+    launch_layernorm(c->vx1, C, c->vx1, C, (int)R, C, 1e-6f, nullptr, nullptr, W(c, p + "norm.scale.weight") + bandwidth_id * C,
+                     W(c, p + "norm.shift.weight") + bandwidth_id * C, st);
+    gemm(c, c->vx1, C, W(c, p + "pwconv1.weight"), C, W(c, p + "pwconv1.bias"), nullptr, 0, nullptr, c->vhid, H, R, H, C, ACT_GELU);
+    gemm(c, c->vhid, H, W(c, p + "pwconv2.weight"), H, W(c, p + "pwconv2.bias"), c->vx0, C, W(c, p + "gamma"), c->vx0, C, R, C, H,
+         ACT_NONE);
+  }
+  launch_layernorm(c->vx0, C, c->vx1, C, (int)R, C, 1e-6f, W(c, P + "final_layer_norm.weight"), W(c, P + "final_layer_norm.bias"),
+                   nullptr, nullptr, st);
+  gemm(c, c->vx1, C, c->vc_head_w, C, c->vc_head_b, nullptr, 0, nullptr, c->vo, NBP, R, NBP, C, ACT_NONE);
+  launch_istft_prep(c->vo, NBP, c->vreim, KP, (int)R, st);
+  gemm(c, c->vreim, KP, c->vc_dft, KP, nullptr, nullptr, 0, nullptr, c->vframes, NF, R, NF, KP, ACT_NONE);
+  const long astride = (long)c->cfg.max_new * 320;
+  launch_overlap_add(c->vframes, NF, mb.dev(o_off), mb.dev(o_len), c->vc_win2, c->vaudio, astride, batch, maxT, st);
+  for (int i = 0; i < batch; ++i)
+    HIPCHK(hipMemcpyAsync(audio + (long)i * audio_stride, c->vaudio + (long)i * astride, (size_t)lens[i] * 320 * sizeof(float),
+                          hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  return VX_OK;
+}
+
+int64_t vx_read_tap(vx_ctx* c, const char* name, float* dst, int64_t max_floats) {
+  if (!c || !name || !dst) return VX_EINVAL;
+  auto it = c->taps.find(name);
+  if (it == c->taps.end()) FAIL(VX_ENOTFOUND, "no tap '%s'", name);
+  const int64_t n = std::min<int64_t>((int64_t)it->second.n, max_floats);
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpy(dst, it->second.d, n * sizeof(float), hipMemcpyDeviceToHost));
+  return n;
+}
+
+int vx_prof_enable(vx_ctx* c, int32_t on) {
+  if (!c) return VX_EINVAL;
+  c->prof_on = on != 0;
+  return VX_OK;
+}
+
+int vx_prof_reset(vx_ctx* c) {
+  if (!c) return VX_EINVAL;
+  for (auto& p : c->prof) { p.used = 0; p.bytes = 0; }
+  return VX_OK;
+}
+
+int vx_prof_get(vx_ctx* c, int32_t which, double* total_ms, int64_t* launches, double* algo_bytes) {
+  if (!c || which < 0 || which > 3) return VX_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  ProfClass& p = c->prof[which];
+  double tot = 0;
+  for (size_t i = 0; i + 1 < p.used; i += 2) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]));
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = (int64_t)(p.used / 2);
+  if (algo_bytes) *algo_bytes = p.bytes;
+  return VX_OK;
+}
+
+int vx_last_stats(vx_ctx* c, int64_t* ar_steps, int64_t* frames, double* ar_ms, double* nar_ms) {
+  if (!c) return VX_EINVAL;
+  if (ar_steps) *ar_steps = c->st_steps;
+  if (frames) *frames = c->st_frames;
+  if (ar_ms) *ar_ms = c->st_ar_ms;
+  if (nar_ms) *nar_ms = c->st_nar_ms;
+  return VX_OK;
+}
+
+}  // extern "C"

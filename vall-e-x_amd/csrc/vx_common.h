@@ -1,0 +1,118 @@
+// Shared declarations for the gfx950 VALL-E X engine (internal; the public C-ABI is include/vallex_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vx {
+
+constexpr int D_MODEL = 1024;
+constexpr int N_HEAD = 16;
+constexpr int D_HEAD = 64;
+constexpr int D_FF = 4096;
+constexpr int N_Q = 8;                 // codebooks
+constexpr int AUDIO_VOCAB = 1024;
+constexpr int EOS_ID = 1024;
+constexpr int BOS_ID = 1025;
+constexpr int AR_LOGITS = 1025;
+constexpr int MB = 32;                 // AR micro-batch rows held by one MFMA column block
+constexpr float LN_EPS = 1e-5f;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+
+// ---- big fp32 MFMA GEMM (gemm_f32.hip) -------------------------------------------------------
+// C[m][n] = resid[m][n] + colscale[n] * act(sum_k A[m][k] * W[n][k] + bias[n]),  m<M, n<N
+// N % 128 == 0, K % 32 == 0, all leading dims % 4 == 0; A must be readable for rows < M.
+struct GemmArgs {
+  const float* A; int lda;
+  const float* W; int ldw;
+  const float* bias;        // [N] or null
+  const float* resid; int ldr;   // [M][ldr] or null
+  const float* colscale;    // [N] or null
+  float* C; int ldc;
+  int M, N, K;
+  int act;
+  const int* row_gather;    // optional: A row index per output row (null = identity)
+};
+void launch_gemm_f32(const GemmArgs& g, hipStream_t s);
+
+// ---- row-wise ops (rows.hip) --------------------------------------------------------------------
+// y = (LN(x) * g + b) [* ada_w + ada_b]; any of g/b/ada_* may be null.  C in {1024, 384}.
+void launch_layernorm(const float* x, int ldx, float* y, int ldy, int rows, int C, float eps, const float* g,
+                      const float* b, const float* ada_w, const float* ada_b, hipStream_t s);
+// out[dst? dst[r] : r] = tabA[idA[r]] (+ tabB[idB[r]] if idB && idB[r] >= 0) + alpha * pe[pos[r]]   (rows of 1024)
+void launch_embed_rows(float* out, const int* dst, const float* tabA, const int* idA, const float* tabB,
+                       const int* idB, const float* alpha, const float* pe, const int* pos, int rows, hipStream_t s);
+// y_emb[r] = sum_{j < nj[r]} tabs[j][codes[r*8+j]]   (tabs: 8 table pointers in a device array)
+void launch_nar_yemb_init(float* yemb, const float* const* tabs, const int* codes, const int* nj, int rows,
+                          hipStream_t s);
+// out[dst[r]] = yemb[r] + alpha * pe[pos[r]]
+void launch_add_pe_scatter(float* out, const int* dst, const float* yemb, const float* alpha, const float* pe,
+                           const int* pos, int rows, hipStream_t s);
+// yemb[rowidx[i]] += tab[tok[i]]
+void launch_embed_accum(float* yemb, const int* rowidx, const float* tab, const int* tok, int n, hipStream_t s);
+// idx[r] = argmax_n x[r][n] (first max), n < N
+void launch_argmax_rows(const float* x, int ldx, int rows, int N, int* idx, hipStream_t s);
+// copy K,V of packed prefill rows into the cache: qkv [M][3072] -> cache[(b*H+h)*Tmax + t][64]
+void launch_kv_scatter(const float* qkv, const int* row_b, const int* row_t, int M, float* kc, float* vc, int Tmax,
+                       hipStream_t s);
+// out[r] = W[r] . e + b[r]  (tiny GEMV used once at load for the AdaLN stage projections)
+void launch_gemv(const float* W, const float* e, const float* b, float* out, int N, int K, hipStream_t s);
+
+// ---- full-sequence attention (attn_full.hip) ---------------------------------------------------
+// qkv packed rows [M][3072] (q|k|v, heads = contiguous 64-wide slices, modules/activation.py:144-147).
+// Sequence b owns rows [seq_off[b], seq_off[b]+seq_len[b]).  prefix_len[b] = S_b for the AR prefix-LM mask
+// (text rows see text only; audio rows see all text + causal audio, models/vallex.py:535-549), or null for
+// the unmasked NAR attention.
+void launch_attn_full(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
+                      int batch, int max_len, hipStream_t s);
+
+// ---- AR decode step (decode.hip) ---------------------------------------------------------------
+// packed skinny-GEMM weight image: tiles of 32 n-rows x 8 k, lane-linear (see decode.hip)
+void launch_pack_weight(const float* W, int N, int K, float* Wp, int Npad, hipStream_t s);
+// partial[ks][b][n] = sum_{k in slice ks} x[b][k] * W[n][k];  xp is the packed activation image.
+void launch_skinny_gemm(const float* Wp, const float* xp, float* partial, int Npad, int K, int splitk,
+                        hipStream_t s);
+// h[b] = (resid? resid[b] : 0) + sum_ks partial[ks][b] + bias ; xp = pack(LN(h)*g+b)   (N = 1024)
+void launch_dec_reduce_ln_pack(const float* partial, int splitk, int npad, const float* bias, const float* resid,
+                               float* h, const float* g, const float* b, float* xp, int batch, hipStream_t s);
+// xp(K=4096) = pack(relu(sum_ks partial + bias))
+void launch_dec_reduce_relu_pack(const float* partial, int splitk, const float* bias, float* xp, int batch,
+                                 hipStream_t s);
+// h[b] = tab[tok[b]] + alpha*pe[pos[b]] ; xp = pack(LN(h))  -- start of a decode step
+void launch_dec_embed_ln_pack(const int* tok, const int* pos, const float* tab, const float* alpha, const float* pe,
+                              float* h, const float* g, const float* b, float* xp, int batch, hipStream_t s);
+// one-token attention over the cache, per (b, head, split); appends the new k/v (from the QKV partials).
+void launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias, float* kc, float* vc, int Tmax,
+                     const int* ctx_len, const int* active, float* xp_out, float* part_o, float* part_ml, int nsplit,
+                     int batch, hipStream_t s);
+void launch_dec_attn_combine(const float* part_o, const float* part_ml, int nsplit, const int* active, float* xp_out,
+                             int batch, hipStream_t s);
+struct SampleArgs {
+  const float* partial; int splitk; int npad;     // logits partials [splitk][MB][npad]
+  int top_k; float temperature;
+  const float* uniforms; int uniforms_stride;     // [steps][batch] or null
+  unsigned long long seed;
+  int force_eos_at;
+  int commit;                                      // 0: only reduce (and export) the logits
+  int* cur_tok; int* cur_pos; int* ctx_len; int* n_gen; int* active; const int* text_len;
+  int* gen; int gen_stride;                        // generated ids [b][gen_stride]
+  float* logits_out;                               // optional [MB][1025] copy of the reduced logits
+  int batch;
+};
+void launch_dec_sample(const SampleArgs& a, hipStream_t s);
+void launch_dec_force_token(const int* tok, int* cur_tok, int* cur_pos, int* ctx_len, int* n_gen, int* gen,
+                            int gen_stride, const int* active, int batch, hipStream_t s);
+
+// ---- Vocos head (vocos.hip) --------------------------------------------------------------------
+void launch_codebook_sum(const int* codes, const float* codebook, float* feat, int rows, hipStream_t s);
+void launch_im2col7(const float* x, int C, const int* row_t, const int* row_len, float* out, int rows, hipStream_t s);
+void launch_dwconv7(const float* x, const float* w, const float* bias, const int* row_t, const int* row_len,
+                    float* out, int rows, int C, hipStream_t s);
+void launch_istft_prep(const float* o, int ldo, float* reim, int ldr, int rows, hipStream_t s);
+void launch_overlap_add(const float* frames, int ldf, const int* seq_off, const int* seq_len, const float* win2,
+                        float* audio, long audio_stride, int batch, int max_T, hipStream_t s);
+
+}  // namespace vx
