@@ -1,0 +1,116 @@
+"""CPU: host logic of the reference-API mirror (signatures, wire formats, error behaviour) -- everything that must
+happen before the first GPU call."""
+import inspect
+import os
+
+import numpy as np
+import pytest
+
+import vallex_amd
+from oracle import synth
+from oracle.vallex_oracle import sine_pe
+from vallex_amd.models.vallex import VALLE, expected_keys, sine_pe_table
+from vallex_amd.utils import generation as G
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _valle(nl=2):
+    return VALLE(1024, 16, nl, norm_first=True, add_prenet=False, prefix_mode=1, share_embedding=True,
+                 nar_scale_factor=1.0, prepend_bos=True, num_quantizers=8)
+
+
+def test_signatures_match_reference():
+    # models/vallex.py:458-471
+    p = list(inspect.signature(VALLE.inference).parameters)
+    assert p[:12] == ["self", "x", "x_lens", "y", "enroll_x_lens", "top_k", "temperature", "prompt_language",
+                      "text_language", "best_of", "length_penalty", "return_worst"]
+    d = inspect.signature(VALLE.inference).parameters
+    assert d["top_k"].default == -100 and d["temperature"].default == 1.0 and d["best_of"].default == 1
+    # utils/generation.py:92,155
+    assert list(inspect.signature(G.generate_audio).parameters)[:4] == ["text", "prompt", "language", "accent"]
+    g = inspect.signature(G.generate_audio_from_long_text).parameters
+    assert list(g)[:5] == ["text", "prompt", "language", "accent", "mode"] and g["mode"].default == "sliding-window"
+    assert G.SAMPLE_RATE == vallex_amd.SAMPLE_RATE == 24000
+
+
+def test_state_dict_wire_format_strict():
+    assert len(expected_keys(12)) == 374
+    sd = synth.vallex_state_dict(2, 0)
+    m = _valle(2)
+    m.load_state_dict(sd, strict=True)
+    bad = dict(sd)
+    bad.pop("ar_predict_layer.weight")
+    with pytest.raises(RuntimeError, match="missing"):
+        _valle(2).load_state_dict(bad, strict=True)
+    bad = dict(sd)
+    bad["extra.weight"] = np.zeros(1, np.float32)
+    with pytest.raises(RuntimeError, match="unexpected"):
+        _valle(2).load_state_dict(bad, strict=True)
+    with pytest.raises(NotImplementedError):
+        VALLE(512, 8, 2, prefix_mode=1)
+
+
+def test_inference_asserts_like_reference():
+    m = _valle(2)
+    x = np.ones((1, 5), np.int32)
+    y = np.zeros((1, 4, 8), np.int32)
+    with pytest.raises(AssertionError):
+        m.inference(x[0], np.array([5]), y, 2, prompt_language="en", text_language="en")        # x.ndim
+    with pytest.raises(AssertionError):
+        m.inference(x, np.array([5]), y[0], 2, prompt_language="en", text_language="en")        # y.ndim
+    with pytest.raises(AssertionError):
+        m.inference(x, np.array([5]), np.zeros((2, 4, 8), np.int32), 2, prompt_language="en", text_language="en")
+    with pytest.raises(AssertionError):
+        m.inference(x, np.array([0]), y, 2, prompt_language="en", text_language="en")           # x_lens > 0
+    with pytest.raises(NotImplementedError):
+        m.inference(x, np.array([5]), y, 2, prompt_language="en", text_language="en", best_of=5)
+
+
+def test_language_rows_and_model_ids():
+    m = _valle(2)
+    assert m.language_ID == {"en": 0, "zh": 1, "ja": 2}                     # models/vallex.py:439-443
+    assert G.code2lang == {0: "zh", 1: "ja", 2: "en"}                      # macros.py:15-19 (different table!)
+    np.testing.assert_array_equal(m._lang_row(5, 2, "ja", "en"), [2, 2, 0, 0, 0])
+    np.testing.assert_array_equal(m._lang_row(5, 2, "zh", ["en", "zh", "ja"]), [1, 1, 0, 1, 2])
+    with pytest.raises(KeyError):
+        m._lang_row(3, 1, "fr", "en")
+
+
+def test_pe_table_is_the_reference_table():
+    np.testing.assert_array_equal(sine_pe_table(300), sine_pe(300).numpy())
+
+
+def test_generation_errors_before_any_gpu_work(tmp_path, monkeypatch):
+    monkeypatch.setattr(G, "model", None)
+    monkeypatch.setattr(G, "vocos", None)
+    with pytest.raises(RuntimeError, match="preload_models"):
+        G.generate_audio([5, 6, 7], language="en")
+    with pytest.raises(FileNotFoundError):
+        G.preload_models(checkpoint=str(tmp_path / "nope.pt"))
+    monkeypatch.setattr(G, "model", object())
+    monkeypatch.setattr(G, "vocos", object())
+    with pytest.raises(ValueError, match="Cannot find prompt"):
+        G.generate_audio([5, 6, 7], prompt="no_such_preset", language="en")
+    with pytest.raises(ValueError, match="No such mode"):
+        G.generate_audio_from_long_text([[5, 6]], prompt="x", language="en", mode="bogus")
+    with pytest.raises(KeyError):
+        G.generate_audio([5, 6, 7], language="fr")
+    with pytest.raises(ValueError, match="Empty text"):
+        G.generate_audio([], language="en")
+    with pytest.raises(RuntimeError, match="language detector"):
+        G.generate_audio("hello", language="auto")
+    with pytest.raises(RuntimeError, match="text front-end"):
+        G.generate_audio("hello", language="en")
+
+
+def test_npz_prompt_wire_format():
+    a, t, lang = G._load_prompt(os.path.join(GOLD, "presets", "librispeech_1.npz"))
+    assert a.shape == (1, 225, 8) and t.shape == (1, 58) and lang == "en" and a.dtype == np.int32
+    monkey = G.PRESET_DIRS
+    try:
+        G.PRESET_DIRS = [os.path.join(GOLD, "presets") + os.sep]
+        a, t, lang = G._load_prompt("cafe")                               # preset name lookup (utils/generation.py:103-110)
+        assert lang == "ja"
+    finally:
+        G.PRESET_DIRS = monkey

@@ -135,3 +135,31 @@ def test_vocos_head_matches_oracle():
         rms_err = float(np.sqrt(np.mean((a - ref) ** 2)))
         assert rms_err <= 1e-4, rms_err
         assert abs(np.sqrt(np.mean(a ** 2)) - np.sqrt(np.mean(ref ** 2))) <= 1e-4
+
+
+def test_generate_audio_api_end_to_end():
+    """utils.generation drop-in: preset .npz in, float32 waveform out; deterministic via injected uniforms, checked
+    against reference-arithmetic run on the CPU (oracle AR+NAR, Vocos restatement)."""
+    import os
+    from vallex_amd.utils import generation as G
+    sd = synth.vallex_state_dict(2, 11)
+    vsd = synth.vocos_state_dict(2)
+    G.preload_models(state_dict=sd, vocos_state_dict=vsd, num_layers=2, max_new=320, max_prompt=400, max_text=256,
+                     max_batch=4)
+    preset = os.path.join(os.path.dirname(__file__), "golden", "presets", "paimon.npz")
+    ids = synth.synth_text(14, 3)
+    us = synth.uniforms(64, 1, 99)[:, 0]
+    wav = G.generate_audio(ids, prompt=preset, language="en", uniforms=us, force_eos_at=24)
+    assert wav.dtype == np.float32 and wav.ndim == 1 and wav.shape[0] == 24 * 320 and np.isfinite(wav).all()
+    d = np.load(preset)
+    text = np.concatenate([d["text_tokens"][0], ids])[None]
+    orc = VallexOracle(sd, 2)
+    codes = orc.inference(text, np.array([text.shape[1]]), d["audio_tokens"], d["text_tokens"].shape[1], top_k=-100,
+                          temperature=1.0, prompt_language="zh", text_language="en", uniforms=us, force_eos_at=24)
+    ref = VocosOracle(vsd).decode_codes(codes, 2)[0]
+    assert float(np.sqrt(np.mean((wav - ref) ** 2))) <= 1e-4
+    # long-text, fixed-prompt mode: two pre-split "sentences" of ids
+    G.rng = np.random.default_rng(0)
+    wav2 = G.generate_audio_from_long_text([ids, synth.synth_text(9, 4)], prompt=preset, language="en",
+                                           mode="fixed-prompt", uniforms=us, force_eos_at=10)
+    assert wav2.shape[0] == 2 * 10 * 320 and np.isfinite(wav2).all()
