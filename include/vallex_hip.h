@@ -118,6 +118,11 @@ int64_t vx_read_tap(vx_ctx* ctx, const char* name, float* dst, int64_t max_float
 int vx_prof_enable(vx_ctx* ctx, int32_t on);
 int vx_prof_get(vx_ctx* ctx, int32_t which, double* total_ms, int64_t* launches, double* algo_bytes);
 int vx_prof_reset(vx_ctx* ctx);
+/* GPU-bound micro-replay of one decode kernel on the state the last AR run left behind: `reps` back-to-back launches
+ * between ONE event pair (eager per-launch events pick up host launch gaps; events recorded inside a hipGraph cannot be
+ * timed on ROCm 7.2).  which 0: dec_attn with every row at context prefill_len + gen_offset; which 1: the four
+ * weight-streaming GEMMs of a layer.  avg_us = per launch; algo_bytes = algorithmic bytes per launch. */
+int vx_bench_kernel(vx_ctx* ctx, int32_t which, int32_t reps, int32_t gen_offset, double* avg_us, double* algo_bytes);
 /* counters of the last vx_infer: AR steps run, generated frames, AR / NAR wall milliseconds (stream-synchronised) */
 int vx_last_stats(vx_ctx* ctx, int64_t* ar_steps, int64_t* frames, double* ar_ms, double* nar_ms);
 

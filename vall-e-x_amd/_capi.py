@@ -45,7 +45,7 @@ class vx_sampling(C.Structure):
 # every symbol include/vallex_hip.h declares (tests/test_abi.py checks the library exports exactly these)
 SYMBOLS = ["vx_create", "vx_destroy", "vx_last_error", "vx_synchronize", "vx_load_tensor", "vx_finalize_weights",
            "vx_infer", "vx_vocos_decode", "vx_ar_prefill", "vx_ar_logits", "vx_ar_step", "vx_nar", "vx_read_tap",
-           "vx_prof_enable", "vx_prof_get", "vx_prof_reset", "vx_last_stats"]
+           "vx_prof_enable", "vx_prof_get", "vx_prof_reset", "vx_bench_kernel", "vx_last_stats"]
 
 _lib = None
 
@@ -81,6 +81,7 @@ def load_library() -> C.CDLL:
     lib.vx_prof_enable.argtypes = [ctx, C.c_int32]
     lib.vx_prof_get.argtypes = [ctx, C.c_int32, P(C.c_double), P(C.c_int64), P(C.c_double)]
     lib.vx_prof_reset.argtypes = [ctx]
+    lib.vx_bench_kernel.argtypes = [ctx, C.c_int32, C.c_int32, C.c_int32, P(C.c_double), P(C.c_double)]
     lib.vx_last_stats.argtypes = [ctx, P(C.c_int64), P(C.c_int64), P(C.c_double), P(C.c_double)]
     for name in SYMBOLS:
         fn = getattr(lib, name)
@@ -231,8 +232,9 @@ class Engine:
         return out[: int(got)]
 
     # ---- measurement ----
-    def prof_enable(self, on: bool):
-        self._chk(self.lib.vx_prof_enable(self.ctx, int(on)))
+    def prof_enable(self, level):
+        """0 off; 1 per-launch events on every class (AR step runs eagerly); 2 full-sequence classes only."""
+        self._chk(self.lib.vx_prof_enable(self.ctx, int(level)))
 
     def prof_reset(self):
         self._chk(self.lib.vx_prof_reset(self.ctx))
@@ -241,6 +243,11 @@ class Engine:
         ms, n, by = C.c_double(), C.c_int64(), C.c_double()
         self._chk(self.lib.vx_prof_get(self.ctx, which, C.byref(ms), C.byref(n), C.byref(by)))
         return ms.value, n.value, by.value
+
+    def bench_kernel(self, which: int, reps: int, gen_offset: int = 0):
+        us, by = C.c_double(), C.c_double()
+        self._chk(self.lib.vx_bench_kernel(self.ctx, which, reps, gen_offset, C.byref(us), C.byref(by)))
+        return us.value, by.value
 
     def last_stats(self):
         a, f, am, nm = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()

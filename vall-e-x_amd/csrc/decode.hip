@@ -50,8 +50,16 @@ void launch_pack_weight(const float* W, int N, int K, float* Wp, int Npad, hipSt
 // skinny GEMM: partial[ks][b][n] = sum_{k in slice ks} x[b][k] * W[n][k]
 // grid = (Npad/32, splitk); 4 waves split the block's K slice and reduce through LDS.
 // ------------------------------------------------------------------------------------------------------------
+// OUT 0: raw split-K partial slab [ks][b][n] (row-major per batch row; consumers: dec_attn, dec_reduce_ln_pack, sample)
+// OUT 1: raw split-K partial slab in the PACKED-x image of the next GEMM (whose k is this GEMM's n):
+//        out[ks][((nt*4 + g4)*64 + lane)*4 + j] -- one coalesced 1-KiB store per g4
+// XIN 0: x fragment = packed image as is
+// XIN 1: x fragment = relu(x0 + x1 + bias[k])  with x1 = x0 + xslab floats: the producer was an OUT-1 GEMM with split-K 2
+//        (linear1's bias + ReLU, modules/transformer.py:371-373, folded into linear2's operand load)
+template <int OUT, int XIN>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restrict__ Wp, const float* __restrict__ xp,
-                                                          float* __restrict__ partial, int Npad, int K, int splitk) {
+                                                          float* __restrict__ out, const float* __restrict__ xbias,
+                                                          long xslab, int Npad, int K, int splitk) {
   __shared__ __attribute__((aligned(16))) float red[3 * 16 * 64];
   const int nt = blockIdx.x, ks = blockIdx.y;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -67,10 +75,20 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
 
   for (int i = 0; i < kb_per_wave; i += 8) {
     f32x4 w[8], x[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + (long)(i + u) * 64);
+    // x first: it is L2-resident and returns early, so the MFMAs can start as soon as the first weight tile lands
 #pragma unroll
     for (int u = 0; u < 8; ++u) x[u] = xq[(long)(i + u) * 64];
+    if (XIN == 1) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const f32x4 x1 = *(reinterpret_cast<const f32x4*>(xp + xslab) + (long)(kb0 + i + u) * 64 + lane);
+        const f32x4 bi = *reinterpret_cast<const f32x4*>(xbias + (kb0 + i + u) * 8 + 4 * (lane >> 5));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[u][e] = fmaxf((x[u][e] + x1[e]) + bi[e], 0.f);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + (long)(i + u) * 64);
 #pragma unroll
     for (int u = 0; u < 8; ++u)
 #pragma unroll
@@ -88,136 +106,255 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
     for (int w2 = 0; w2 < 3; ++w2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] += red[(w2 * 16 + r) * 64 + lane];
-    float* dst = partial + ((long)ks * MB + (lane & 31)) * Npad + nt * 32 + 4 * (lane >> 5);
+    if (OUT == 0) {
+      float* dst = out + ((long)ks * MB + (lane & 31)) * Npad + nt * 32 + 4 * (lane >> 5);
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      f32x4 t = {acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]};
-      *reinterpret_cast<f32x4*>(dst + g4 * 8) = t;
+      for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 t = {acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]};
+        *reinterpret_cast<f32x4*>(dst + g4 * 8) = t;
+      }
+    } else {
+      float* dst = out + (long)ks * MB * Npad;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 t = {acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]};
+        *reinterpret_cast<f32x4*>(dst + (((long)(nt * 4 + g4) * 64) + lane) * 4) = t;
+      }
     }
   }
 }
 
 void launch_skinny_gemm(const float* Wp, const float* xp, float* partial, int Npad, int K, int splitk,
                         hipStream_t s) {
-  hipLaunchKernelGGL(skinny_gemm_kernel, dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, xp, partial, Npad, K, splitk);
+  hipLaunchKernelGGL((skinny_gemm_kernel<0, 0>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, xp, partial, nullptr,
+                     0L, Npad, K, splitk);
+}
+
+// linear1: raw split-K(2) partials written directly in linear2's packed-x image
+void launch_skinny_gemm_packed_out(const float* Wp, const float* xp, float* out_pk, int Npad, int K, int splitk,
+                                   hipStream_t s) {
+  hipLaunchKernelGGL((skinny_gemm_kernel<1, 0>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, xp, out_pk, nullptr, 0L,
+                     Npad, K, splitk);
+}
+
+// linear2: x = relu(pk[0] + pk[1] + bias1) formed while loading the operand
+void launch_skinny_gemm_relu_in(const float* Wp, const float* x_pk, const float* xbias, long xslab, float* partial,
+                                int Npad, int K, int splitk, hipStream_t s) {
+  hipLaunchKernelGGL((skinny_gemm_kernel<0, 1>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, x_pk, partial, xbias,
+                     xslab, Npad, K, splitk);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// linear1 (N = 4096) with its epilogue fused and NO split-K: 16-row weight tiles on v_mfma_f32_16x16x4_f32 give
+// 256 workgroups (one per CU), 8 waves each splitting K; the 32 batch rows are two 16-wide MFMA column blocks that
+// share one weight fragment.  out = relu(x.W^T + bias) is written straight into linear2's packed-x image
+// (modules/transformer.py:371-373).
+//   weight image: W16[((nt*KB16 + kb)*64 + lane)*4 + j] = W[16nt + (lane&15)][16kb + 4(lane>>4) + j]   (KB16 = K/16)
+//   x fragment  : read from the 32-row packed image: x[b = 16half + (lane&15)][16kb + 4(lane>>4) + j]
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weight16_kernel(const float* __restrict__ W, int N, int K,
+                                                            float* __restrict__ Wp) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;         // float4 index
+  const int KB = K / 16;
+  const long total = (long)(N / 16) * KB * 64;
+  if (i >= total) return;
+  const int lane = (int)(i & 63);
+  const long t = i >> 6;
+  const int kb = (int)(t % KB), nt = (int)(t / KB);
+  const int n = nt * 16 + (lane & 15), k = kb * 16 + 4 * (lane >> 4);
+  *reinterpret_cast<f32x4*>(Wp + i * 4) = *reinterpret_cast<const f32x4*>(W + (long)n * K + k);
+}
+
+void launch_pack_weight16(const float* W, int N, int K, float* Wp, hipStream_t s) {
+  const long total = (long)(N / 16) * (K / 16) * 64;
+  hipLaunchKernelGGL(pack_weight16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W, N, K, Wp);
+}
+
+constexpr int S16_WAVES = 8;
+
+__global__ __launch_bounds__(S16_WAVES * 64) void skinny16_relu_pack_kernel(const float* __restrict__ W16,
+                                                                            const float* __restrict__ xp,
+                                                                            const float* __restrict__ bias,
+                                                                            float* __restrict__ xp_out, int K) {
+  __shared__ __attribute__((aligned(16))) float red[(S16_WAVES - 1) * 8 * 64];
+  const int nt = blockIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int KB = K / 16, per = KB / S16_WAVES;        // K = 1024: 64 k-blocks, 8 per wave
+  const int kb0 = wid * per;
+  const int kg = lane >> 4, bl = lane & 15;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(W16) + ((long)nt * KB + kb0) * 64 + lane;
+  // float4 index of x[b = bl (+16)][16 kb + 4 kg ..] in the 32-row image: (2kb + (kg>>1))*64 + b + 32*(kg&1)
+  const f32x4* xq = reinterpret_cast<const f32x4*>(xp) + (long)(2 * kb0 + (kg >> 1)) * 64 + bl + 32 * (kg & 1);
+
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < per; i += 8) {
+    f32x4 w[8], x0[8], x1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { x0[u] = xq[(long)(i + u) * 128]; x1[u] = xq[(long)(i + u) * 128 + 16]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + (long)(i + u) * 64);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][j], x0[u][j], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][j], x1[u][j], acc1, 0, 0, 0);
+      }
+  }
+  // acc{h}[r] = out[b = 16h + (lane&15)][n = 16nt + 4(lane>>4) + r]
+  if (wid > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      red[((wid - 1) * 8 + r) * 64 + lane] = acc0[r];
+      red[((wid - 1) * 8 + 4 + r) * 64 + lane] = acc1[r];
+    }
+  }
+  __syncthreads();
+  if (wid == 0) {
+#pragma unroll
+    for (int w2 = 0; w2 < S16_WAVES - 1; ++w2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc0[r] += red[(w2 * 8 + r) * 64 + lane];
+        acc1[r] += red[(w2 * 8 + 4 + r) * 64 + lane];
+      }
+    const f32x4 bi = *reinterpret_cast<const f32x4*>(bias + nt * 16 + 4 * kg);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acc0[r] = fmaxf(acc0[r] + bi[r], 0.f); acc1[r] = fmaxf(acc1[r] + bi[r], 0.f); }
+    // n = 16nt + 4kg + r  ->  linear2's k: kb = 2nt + (kg>>1), hi = kg&1, j = r
+    float* o = xp_out + (((long)(2 * nt + (kg >> 1)) * 64) + bl + 32 * (kg & 1)) * 4;
+    *reinterpret_cast<f32x4*>(o) = acc0;
+    *reinterpret_cast<f32x4*>(o + 16 * 4) = acc1;
+  }
+}
+
+void launch_skinny16_relu_pack(const float* W16, const float* xp, const float* bias, float* xp_out, int N, int K,
+                               hipStream_t s) {
+  hipLaunchKernelGGL(skinny16_relu_pack_kernel, dim3(N / 16), dim3(S16_WAVES * 64), 0, s, W16, xp, bias, xp_out, K);
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // row kernels of the step: one 256-thread block per batch row, thread t owns columns 4t..4t+3 of the 1024.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+__device__ __forceinline__ float wave_sum64(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  const int wid = threadIdx.x >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh[wid] = v;
-  __syncthreads();
-  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  return v;
 }
 
-// LayerNorm of the row held as one float4 per thread, written in the packed-x image (K = 1024).
-__device__ __forceinline__ void ln_pack_row(f32x4 v, int b, const float* __restrict__ g,
-                                            const float* __restrict__ bb, float* __restrict__ xp, float* sh) {
-  const int t = threadIdx.x;
-  const float mean = block_sum_256(v[0] + v[1] + v[2] + v[3], sh) * (1.0f / D_MODEL);
+// One 64-lane wave per batch row: lane l owns float4 columns c4 = l + 64 i (i < 4) of the 1024 -- no LDS, no barriers.
+// LayerNorm (two-pass, registers) written in the packed-x image: float4 column c4 -> kb = c4>>1, hi = c4&1.
+__device__ __forceinline__ void ln_pack_row(const f32x4 (&v)[4], int b, const f32x4 (&gg)[4], const f32x4 (&be)[4],
+                                            float* __restrict__ xp) {
+  const int lane = threadIdx.x;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  const float mean = wave_sum64(s) * (1.0f / D_MODEL);
   float q = 0.f;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q += d * d; }
-  const float rstd = 1.0f / sqrtf(block_sum_256(q, sh) * (1.0f / D_MODEL) + LN_EPS);
-  const f32x4 gg = *reinterpret_cast<const f32x4*>(g + t * 4);
-  const f32x4 be = *reinterpret_cast<const f32x4*>(bb + t * 4);
-  f32x4 o;
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * gg[e] + be[e];
-  // columns 4t..4t+3: kb = t>>1, hi = t&1
-  *reinterpret_cast<f32x4*>(xp + (((long)(t >> 1) * 64) + b + 32 * (t & 1)) * 4) = o;
+    for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum64(q) * (1.0f / D_MODEL) + LN_EPS);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c4 = lane + 64 * i;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gg[i][e] + be[i][e];
+    *reinterpret_cast<f32x4*>(xp + (((long)(c4 >> 1) * 64) + b + 32 * (c4 & 1)) * 4) = o;
+  }
 }
 
 // h[b] = resid[b] + (sum_ks partial[ks][b] + bias);  xp = pack(LN(h)).  partial may be null (splitk = 0).
 // modules/transformer.py:345-346 (x = x + attn_out ; x = x + ff(norm2(x))) fused with the next norm.
-__global__ __launch_bounds__(256) void dec_reduce_ln_pack_kernel(const float* __restrict__ partial, int splitk,
-                                                                 int npad, const float* __restrict__ bias,
-                                                                 const float* __restrict__ resid,
-                                                                 float* __restrict__ h, const float* __restrict__ g,
-                                                                 const float* __restrict__ bb,
-                                                                 float* __restrict__ xp) {
-  __shared__ float sh[4];
-  const int b = blockIdx.x, t = threadIdx.x;
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (splitk > 0) {
-    v = *reinterpret_cast<const f32x4*>(partial + (long)b * npad + t * 4);
-    for (int ks = 1; ks < splitk; ++ks) {
-      const f32x4 p = *reinterpret_cast<const f32x4*>(partial + ((long)ks * MB + b) * npad + t * 4);
+template <int SK>
+__global__ __launch_bounds__(64) void dec_reduce_ln_pack_kernel(const float* __restrict__ partial, int npad,
+                                                                const float* __restrict__ bias,
+                                                                const float* __restrict__ resid,
+                                                                float* __restrict__ h, const float* __restrict__ g,
+                                                                const float* __restrict__ bb,
+                                                                float* __restrict__ xp) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  f32x4 v[4], gg[4], be[4], r[4], bi[4], p[SK > 0 ? SK : 1][4];
+  // every load of the kernel is independent: issue all of them, then reduce (slab order ks ascending)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += p[e];
-    }
-    if (bias) {
-      const f32x4 bi = *reinterpret_cast<const f32x4*>(bias + t * 4);
+  for (int ks = 0; ks < SK; ++ks)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += bi[e];
-    }
+    for (int i = 0; i < 4; ++i)
+      p[ks][i] = *reinterpret_cast<const f32x4*>(partial + ((long)ks * MB + b) * npad + (lane + 64 * i) * 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    gg[i] = *reinterpret_cast<const f32x4*>(g + c);
+    be[i] = *reinterpret_cast<const f32x4*>(bb + c);
+    if (resid) r[i] = *reinterpret_cast<const f32x4*>(resid + (long)b * D_MODEL + c);
+    if (SK > 0 && bias) bi[i] = *reinterpret_cast<const f32x4*>(bias + c);
   }
-  if (resid) {
-    const f32x4 r = *reinterpret_cast<const f32x4*>(resid + (long)b * D_MODEL + t * 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = r[e] + v[e];
+  for (int i = 0; i < 4; ++i) {
+    if (SK > 0) {
+      v[i] = p[0][i];
+#pragma unroll
+      for (int ks = 1; ks < SK; ++ks)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] += p[ks][i][e];
+      if (bias)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] += bi[i][e];
+    } else {
+      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (resid)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] = r[i][e] + v[i][e];
+    if (h) *reinterpret_cast<f32x4*>(h + (long)b * D_MODEL + (lane + 64 * i) * 4) = v[i];
   }
-  if (h) *reinterpret_cast<f32x4*>(h + (long)b * D_MODEL + t * 4) = v;
-  ln_pack_row(v, b, g, bb, xp, sh);
+  ln_pack_row(v, b, gg, be, xp);
 }
 
 void launch_dec_reduce_ln_pack(const float* partial, int splitk, int npad, const float* bias, const float* resid,
                                float* h, const float* g, const float* b, float* xp, int batch, hipStream_t s) {
-  hipLaunchKernelGGL(dec_reduce_ln_pack_kernel, dim3(batch), dim3(256), 0, s, partial, splitk, npad, bias, resid, h, g,
-                     b, xp);
-}
-
-// xp(K=4096) = pack(relu(sum_ks partial + bias))   -- linear1 epilogue (modules/transformer.py:371-373)
-__global__ __launch_bounds__(256) void dec_reduce_relu_pack_kernel(const float* __restrict__ partial, int splitk,
-                                                                   const float* __restrict__ bias,
-                                                                   float* __restrict__ xp) {
-  const int b = blockIdx.x, c4 = blockIdx.y * 256 + threadIdx.x;       // float4 column index, 0..1023
-  f32x4 v = *reinterpret_cast<const f32x4*>(partial + (long)b * D_FF + c4 * 4);
-  for (int ks = 1; ks < splitk; ++ks) {
-    const f32x4 p = *reinterpret_cast<const f32x4*>(partial + ((long)ks * MB + b) * D_FF + c4 * 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] += p[e];
-  }
-  const f32x4 bi = *reinterpret_cast<const f32x4*>(bias + c4 * 4);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bi[e], 0.f);
-  *reinterpret_cast<f32x4*>(xp + (((long)(c4 >> 1) * 64) + b + 32 * (c4 & 1)) * 4) = v;
-}
-
-void launch_dec_reduce_relu_pack(const float* partial, int splitk, const float* bias, float* xp, int batch,
-                                 hipStream_t s) {
-  hipLaunchKernelGGL(dec_reduce_relu_pack_kernel, dim3(batch, 4), dim3(256), 0, s, partial, splitk, bias, xp);
+  if (splitk == 0)
+    hipLaunchKernelGGL((dec_reduce_ln_pack_kernel<0>), dim3(batch), dim3(64), 0, s, partial, npad, bias, resid, h, g, b, xp);
+  else if (splitk == 4)
+    hipLaunchKernelGGL((dec_reduce_ln_pack_kernel<4>), dim3(batch), dim3(64), 0, s, partial, npad, bias, resid, h, g, b, xp);
+  else
+    hipLaunchKernelGGL((dec_reduce_ln_pack_kernel<8>), dim3(batch), dim3(64), 0, s, partial, npad, bias, resid, h, g, b, xp);
 }
 
 // Start of a step: embed the newest token of each row at its audio position (the reference re-embeds all of y and
 // keeps the last row, models/vallex.py:529-531,552-553), then norm1 of layer 0.
-__global__ __launch_bounds__(256) void dec_embed_ln_pack_kernel(const int* __restrict__ tok,
-                                                                const int* __restrict__ pos,
-                                                                const float* __restrict__ tab,
-                                                                const float* __restrict__ alpha,
-                                                                const float* __restrict__ pe, float* __restrict__ h,
-                                                                const float* __restrict__ g,
-                                                                const float* __restrict__ bb,
-                                                                float* __restrict__ xp) {
-  __shared__ float sh[4];
-  const int b = blockIdx.x, t = threadIdx.x;
-  f32x4 v = *reinterpret_cast<const f32x4*>(tab + (long)tok[b] * D_MODEL + t * 4);
-  const f32x4 p = *reinterpret_cast<const f32x4*>(pe + (long)pos[b] * D_MODEL + t * 4);
+__global__ __launch_bounds__(64) void dec_embed_ln_pack_kernel(const int* __restrict__ tok,
+                                                               const int* __restrict__ pos,
+                                                               const float* __restrict__ tab,
+                                                               const float* __restrict__ alpha,
+                                                               const float* __restrict__ pe, float* __restrict__ h,
+                                                               const float* __restrict__ g,
+                                                               const float* __restrict__ bb,
+                                                               float* __restrict__ xp) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const long trow = (long)tok[b] * D_MODEL, prow = (long)pos[b] * D_MODEL;
   const float a = alpha[0];
+  f32x4 v[4], gg[4], be[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(v[e], __fmul_rn(a, p[e]));
-  *reinterpret_cast<f32x4*>(h + (long)b * D_MODEL + t * 4) = v;
-  ln_pack_row(v, b, g, bb, xp, sh);
+  for (int i = 0; i < 4; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    gg[i] = *reinterpret_cast<const f32x4*>(g + c);
+    be[i] = *reinterpret_cast<const f32x4*>(bb + c);
+    v[i] = *reinterpret_cast<const f32x4*>(tab + trow + c);
+    const f32x4 p = *reinterpret_cast<const f32x4*>(pe + prow + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[i][e] = __fadd_rn(v[i][e], __fmul_rn(a, p[e]));
+    *reinterpret_cast<f32x4*>(h + (long)b * D_MODEL + c) = v[i];
+  }
+  ln_pack_row(v, b, gg, be, xp);
 }
 
 void launch_dec_embed_ln_pack(const int* tok, const int* pos, const float* tab, const float* alpha, const float* pe,
                               float* h, const float* g, const float* b, float* xp, int batch, hipStream_t s) {
-  hipLaunchKernelGGL(dec_embed_ln_pack_kernel, dim3(batch), dim3(256), 0, s, tok, pos, tab, alpha, pe, h, g, b, xp);
+  hipLaunchKernelGGL(dec_embed_ln_pack_kernel, dim3(batch), dim3(64), 0, s, tok, pos, tab, alpha, pe, h, g, b, xp);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -237,22 +374,50 @@ __device__ __forceinline__ float dpp_sum16(float x) {
 }
 
 constexpr float NEG_BIG = -1e30f;
-constexpr int ATT_U = 8;              // rows per lane-group in flight (x 4 groups x 4 waves = 128 rows / block iter)
+constexpr int ATT_U = 4;              // rows per lane-group per buffer; two buffers in flight (2 x 8 KiB per wave)
+constexpr int ATT_WAVES = 8;          // 512-thread workgroup
+constexpr int ATT_STRIDE = ATT_WAVES * 4 * ATT_U;   // rows consumed per block iteration
 
-__global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__ qkv_partial, int splitk,
-                                                       const float* __restrict__ qkv_bias, float* __restrict__ kc,
-                                                       float* __restrict__ vc, int Tmax,
-                                                       const int* __restrict__ ctx_len,
-                                                       const int* __restrict__ active, float* __restrict__ xp_out,
-                                                       float* __restrict__ part_o, float* __restrict__ part_ml,
-                                                       int nsplit) {
-  __shared__ __attribute__((aligned(16))) float sh_o[4][64];
-  __shared__ float sh_m[4], sh_l[4];
+__global__ __launch_bounds__(ATT_WAVES * 64) void dec_attn_kernel(const float* __restrict__ qkv_partial, int splitk,
+                                                                  const float* __restrict__ qkv_bias,
+                                                                  float* __restrict__ kc, float* __restrict__ vc,
+                                                                  int Tmax, const int* __restrict__ ctx_len,
+                                                                  const int* __restrict__ active,
+                                                                  float* __restrict__ xp_out,
+                                                                  float* __restrict__ part_o,
+                                                                  float* __restrict__ part_ml, int nsplit) {
+  __shared__ __attribute__((aligned(16))) float sh_o[ATT_WAVES][64];
+  __shared__ float sh_m[ATT_WAVES], sh_l[ATT_WAVES];
   const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
   if (!active[b]) return;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
   const int ctx = ctx_len[b];                 // cached rows INCLUDING the new token (at ctx-1)
   const int npast = ctx - 1;
+  const long head_base = ((long)(b * N_HEAD + h) * Tmax) * D_HEAD;
+  const f32x4* kp = reinterpret_cast<const f32x4*>(kc + head_base) + c;
+  const f32x4* vp = reinterpret_cast<const f32x4*>(vc + head_base) + c;
+
+  // this block's slice of the past rows; this lane-group's rows are first, first + 16*WAVES/4.. (stride per u)
+  const int chunk = ((npast + nsplit - 1) / nsplit + 15) & ~15;
+  const int t0 = sp * chunk;
+  const int t1 = (t0 + chunk < npast) ? t0 + chunk : npast;
+  constexpr int RS = ATT_WAVES * 4;           // row stride between a lane-group's consecutive rows
+  int base = t0 + wid * 4 + g;
+
+  f32x4 kA[ATT_U], vA[ATT_U], kB[ATT_U], vB[ATT_U];
+#define ATT_LOAD(KK, VV, BASE)                                             \
+  _Pragma("unroll") for (int u = 0; u < ATT_U; ++u) {                       \
+    int t = (BASE) + RS * u;                                               \
+    t = t < t1 ? t : t1 - 1;                                               \
+    KK[u] = __builtin_nontemporal_load(kp + (long)t * 16);                 \
+  }                                                                        \
+  _Pragma("unroll") for (int u = 0; u < ATT_U; ++u) {                       \
+    int t = (BASE) + RS * u;                                               \
+    t = t < t1 ? t : t1 - 1;                                               \
+    VV[u] = __builtin_nontemporal_load(vp + (long)t * 16);                 \
+  }
+  // first tile in flight BEFORE the q/k/v reduction below (it does not depend on q)
+  if (base < t1) { ATT_LOAD(kA, vA, base) }
 
   // q / k_new / v_new of this head: reduce the QKV split-K partials + bias (in_proj, modules/activation.py:144)
   f32x4 q4, k4, v4;
@@ -277,58 +442,47 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
 #pragma unroll
     for (int e = 0; e < 4; ++e) { q4[e] = (q4[e] + b0[e]) * 0.125f; k4[e] += b1[e]; v4[e] += b2[e]; }
   }
-  const long head_base = ((long)(b * N_HEAD + h) * Tmax) * D_HEAD;
   if (sp == 0 && wid == 0 && g == 0) {        // in-place append: present = (k, v) (modules/activation.py:151-157)
     *reinterpret_cast<f32x4*>(kc + head_base + (long)npast * D_HEAD + c * 4) = k4;
     *reinterpret_cast<f32x4*>(vc + head_base + (long)npast * D_HEAD + c * 4) = v4;
   }
 
-  // this block's slice of the past rows
-  const int chunk = ((npast + nsplit - 1) / nsplit + 15) & ~15;
-  const int t0 = sp * chunk;
-  const int t1 = (t0 + chunk < npast) ? t0 + chunk : npast;
-
   float m = NEG_BIG, l = 0.f;
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
-  const f32x4* kp = reinterpret_cast<const f32x4*>(kc + head_base) + c;
-  const f32x4* vp = reinterpret_cast<const f32x4*>(vc + head_base) + c;
-
-  for (int base = t0 + wid * 4 + g; base < t1; base += 16 * ATT_U) {
-    f32x4 kk[ATT_U], vv[ATT_U];
-#pragma unroll
-    for (int u = 0; u < ATT_U; ++u) {
-      int t = base + 16 * u;
-      t = t < t1 ? t : t1 - 1;
-      kk[u] = __builtin_nontemporal_load(kp + (long)t * 16);
-    }
-#pragma unroll
-    for (int u = 0; u < ATT_U; ++u) {
-      int t = base + 16 * u;
-      t = t < t1 ? t : t1 - 1;
-      vv[u] = __builtin_nontemporal_load(vp + (long)t * 16);
-    }
-    float sc[ATT_U];
-    float m_new = m;
-#pragma unroll
-    for (int u = 0; u < ATT_U; ++u) {
-      float d = q4[0] * kk[u][0] + q4[1] * kk[u][1] + q4[2] * kk[u][2] + q4[3] * kk[u][3];
-      d = dpp_sum16(d);
-      sc[u] = (base + 16 * u < t1) ? d : NEG_BIG;
-      m_new = fmaxf(m_new, sc[u]);
-    }
-    const float alpha = expf(m - m_new);
-    l *= alpha;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] *= alpha;
-#pragma unroll
-    for (int u = 0; u < ATT_U; ++u) {
-      const float p = (base + 16 * u < t1) ? expf(sc[u] - m_new) : 0.f;
-      l += p;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] += p * vv[u][e];
-    }
-    m = m_new;
+#define ATT_CONSUME(KK, VV, BASE)                                                                  \
+  {                                                                                                \
+    float sc[ATT_U];                                                                               \
+    float m_new = m;                                                                               \
+    _Pragma("unroll") for (int u = 0; u < ATT_U; ++u) {                                             \
+      float d = q4[0] * KK[u][0] + q4[1] * KK[u][1] + q4[2] * KK[u][2] + q4[3] * KK[u][3];         \
+      d = dpp_sum16(d);                                                                            \
+      sc[u] = ((BASE) + RS * u < t1) ? d : NEG_BIG;                                                \
+      m_new = fmaxf(m_new, sc[u]);                                                                 \
+    }                                                                                              \
+    const float alpha = expf(m - m_new);                                                           \
+    l *= alpha;                                                                                    \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) o[e] *= alpha;                                    \
+    _Pragma("unroll") for (int u = 0; u < ATT_U; ++u) {                                             \
+      const float p = ((BASE) + RS * u < t1) ? expf(sc[u] - m_new) : 0.f;                          \
+      l += p;                                                                                      \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) o[e] += p * VV[u][e];                           \
+    }                                                                                              \
+    m = m_new;                                                                                     \
   }
+  // double-buffered stream: the next tile's 8 loads are in flight while the current tile is reduced
+  while (base < t1) {
+    int nb = base + ATT_STRIDE;
+    if (nb < t1) { ATT_LOAD(kB, vB, nb) }
+    ATT_CONSUME(kA, vA, base)
+    base = nb;
+    if (base >= t1) break;
+    nb = base + ATT_STRIDE;
+    if (nb < t1) { ATT_LOAD(kA, vA, nb) }
+    ATT_CONSUME(kB, vB, base)
+    base = nb;
+  }
+#undef ATT_LOAD
+#undef ATT_CONSUME
   // the new token itself (always visible: last mask row is all False, models/vallex.py:535-549)
   if (sp == nsplit - 1 && wid == 0 && g == 0) {
     float d = q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3];
@@ -341,7 +495,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
     m = m_new;
   }
 
-  // combine the 4 lane-groups of the wave (xor 16, 32), then the 4 waves through LDS
+  // combine the 4 lane-groups of the wave (xor 16, 32), then the waves through LDS
 #pragma unroll
   for (int off = 16; off <= 32; off <<= 1) {
     const float m2 = __shfl_xor(m, off, 64), l2 = __shfl_xor(l, off, 64);
@@ -360,11 +514,13 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
   }
   __syncthreads();
   if (wid == 0 && g == 0) {
-    float mt = fmaxf(fmaxf(sh_m[0], sh_m[1]), fmaxf(sh_m[2], sh_m[3]));
+    float mt = NEG_BIG;
+#pragma unroll
+    for (int w = 0; w < ATT_WAVES; ++w) mt = fmaxf(mt, sh_m[w]);
     float lt = 0.f;
     f32x4 ot = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < ATT_WAVES; ++w) {
       const float a = expf(sh_m[w] - mt);
       lt += sh_l[w] * a;
       const f32x4 ow = *reinterpret_cast<const f32x4*>(&sh_o[w][c * 4]);
@@ -388,8 +544,8 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float* __restrict__
 void launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias, float* kc, float* vc, int Tmax,
                      const int* ctx_len, const int* active, float* xp_out, float* part_o, float* part_ml, int nsplit,
                      int batch, hipStream_t s) {
-  hipLaunchKernelGGL(dec_attn_kernel, dim3(N_HEAD, batch, nsplit), dim3(256), 0, s, qkv_partial, splitk, qkv_bias, kc,
-                     vc, Tmax, ctx_len, active, xp_out, part_o, part_ml, nsplit);
+  hipLaunchKernelGGL(dec_attn_kernel, dim3(N_HEAD, batch, nsplit), dim3(ATT_WAVES * 64), 0, s, qkv_partial, splitk,
+                     qkv_bias, kc, vc, Tmax, ctx_len, active, xp_out, part_o, part_ml, nsplit);
 }
 
 __global__ __launch_bounds__(64) void dec_attn_combine_kernel(const float* __restrict__ part_o,
@@ -421,15 +577,6 @@ void launch_dec_attn_combine(const float* part_o, const float* part_ml, int nspl
 // dec_sample: ar_predict_layer logits (split-K partials) -> topk_sampling (models/vallex.py:791-853) -> EOS / cap
 // bookkeeping (models/vallex.py:572-598), one block per row, everything stays on the device.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float block_max_256(float v, float* sh) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
-}
-
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
   x += 0x9E3779B97F4A7C15ull;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -437,79 +584,122 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
   return x ^ (x >> 31);
 }
 
-__global__ __launch_bounds__(256) void dec_sample_kernel(SampleArgs a) {
-  __shared__ float lg[AR_LOGITS + 7];
-  __shared__ float sh[4];
-  __shared__ int sh_i[4];
-  __shared__ int s_tok;
-  const int b = blockIdx.x, t = threadIdx.x;
+__device__ __forceinline__ float wave_max64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum64i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_min64i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// One wave per row.  The 1025 logits live in registers, lane l owning the CONTIGUOUS indices [17l, 17l+17) so the
+// inverse-CDF running sum follows index order (sequential inside a lane, Hillis-Steele across lanes: a fixed,
+// run-to-run deterministic order).
+constexpr int SPL = 17;   // 64 * 17 = 1088 >= 1025
+
+__global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
+  __shared__ float lg[64 * SPL];
+  const int b = blockIdx.x, lane = threadIdx.x;
   const bool act = a.active[b] != 0;
   if (!act && !a.logits_out) return;
 
-  for (int n = t; n < AR_LOGITS; n += 256) {
-    float v = a.partial[(long)b * a.npad + n];
-    for (int ks = 1; ks < a.splitk; ++ks) v += a.partial[((long)ks * MB + b) * a.npad + n];
-    lg[n] = v;
-    if (a.logits_out) a.logits_out[(long)b * AR_LOGITS + n] = v;
+  {
+    float t[SPL];
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) {                 // all SPL x splitk loads are independent: issue, then add
+      const int n = lane + 64 * i;
+      t[i] = -INFINITY;
+      if (n < AR_LOGITS) {
+        float p0 = a.partial[(long)b * a.npad + n];
+        float p1 = a.splitk > 1 ? a.partial[((long)1 * MB + b) * a.npad + n] : 0.f;
+        float p2 = a.splitk > 2 ? a.partial[((long)2 * MB + b) * a.npad + n] : 0.f;
+        float p3 = a.splitk > 3 ? a.partial[((long)3 * MB + b) * a.npad + n] : 0.f;
+        t[i] = ((p0 + p1) + p2) + p3;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) {
+      const int n = lane + 64 * i;
+      lg[n] = t[i];
+      if (a.logits_out && n < AR_LOGITS) a.logits_out[(long)b * AR_LOGITS + n] = t[i];
+    }
   }
   __syncthreads();
   if (!act || !a.commit) return;
 
-  if (a.temperature != 1.0f) {                                   // :845-846
-    for (int n = t; n < AR_LOGITS; n += 256) lg[n] = lg[n] / a.temperature;
-    __syncthreads();
+  float v[SPL];
+#pragma unroll
+  for (int j = 0; j < SPL; ++j) v[j] = lg[lane * SPL + j];        // stride 17 floats: conflict-free
+  if (a.temperature != 1.0f) {                                     // models/vallex.py:845-846
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) v[j] = v[j] / a.temperature;
   }
   float mx = -INFINITY;
-  for (int n = t; n < AR_LOGITS; n += 256) mx = fmaxf(mx, lg[n]);
-  mx = block_max_256(mx, sh);
+#pragma unroll
+  for (int j = 0; j < SPL; ++j) mx = fmaxf(mx, v[j]);
+  mx = wave_max64(mx);
 
-  if (a.top_k > 0) {                                              // :803-809, ties with the k-th value are kept
-    const int k = a.top_k < AR_LOGITS ? a.top_k : AR_LOGITS;
+  if (a.top_k > 0 && a.top_k < AR_LOGITS) {                        // :803-809, ties with the k-th value are kept
     float thr = mx, prev = INFINITY;
     int count = 0;
     while (true) {
       float cur = -INFINITY;
-      int cnt = 0;
-      for (int n = t; n < AR_LOGITS; n += 256) { const float v = lg[n]; if (v < prev) cur = fmaxf(cur, v); }
-      cur = block_max_256(cur, sh);
-      for (int n = t; n < AR_LOGITS; n += 256) cnt += (lg[n] == cur);
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-      __syncthreads();
-      if ((t & 63) == 0) sh_i[t >> 6] = cnt;
-      __syncthreads();
-      count += sh_i[0] + sh_i[1] + sh_i[2] + sh_i[3];
+      for (int j = 0; j < SPL; ++j) if (v[j] < prev) cur = fmaxf(cur, v[j]);
+      cur = wave_max64(cur);
+      int cnt = 0;
+#pragma unroll
+      for (int j = 0; j < SPL; ++j) cnt += (v[j] == cur);
+      count += wave_sum64i(cnt);
       thr = cur;
-      if (count >= k || cur == -INFINITY) break;
+      if (count >= a.top_k || cur == -INFINITY) break;
       prev = cur;
     }
-    for (int n = t; n < AR_LOGITS; n += 256) if (lg[n] < thr) lg[n] = -INFINITY;
-    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) if (v[j] < thr) v[j] = -INFINITY;
   }
-  // softmax numerators (F.softmax: exp(x - max) / sum); probabilities are only needed up to the common 1/sum
-  for (int n = t; n < AR_LOGITS; n += 256) lg[n] = expf(lg[n] - mx);
-  __syncthreads();
+  // softmax numerators (F.softmax = exp(x - max) / sum; the common 1/sum cancels in the inverse CDF)
+  float e[SPL], loc = 0.f;
+#pragma unroll
+  for (int j = 0; j < SPL; ++j) { e[j] = expf(v[j] - mx); loc += e[j]; }
+  float incl = loc;                                                // inclusive scan over lanes
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  const float total = __shfl(incl, 63, 64);
+  const int ngen = a.n_gen[b];
+  float u;
+  if (a.uniforms) u = a.uniforms[(long)ngen * a.uniforms_stride + b];
+  else u = (float)(splitmix64(a.seed ^ ((unsigned long long)ngen << 24) ^ (unsigned long long)b) >> 40) *
+           (1.0f / 16777216.0f);
+  const float thresh = u * total;
+  float c = incl - loc;
+  int cand = 0x7fffffff, lastnz = -1;
+#pragma unroll
+  for (int j = 0; j < SPL; ++j) {
+    if (e[j] > 0.f) {
+      c += e[j];
+      lastnz = lane * SPL + j;
+      if (c > thresh && cand == 0x7fffffff) cand = lane * SPL + j;
+    }
+  }
+  cand = wave_min64i(cand);
+  int last_all = lastnz;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) last_all = max(last_all, __shfl_xor(last_all, o, 64));
+  int tok = cand == 0x7fffffff ? last_all : cand;
 
-  if (t == 0) {
-    const int ngen = a.n_gen[b];
-    float u;
-    if (a.uniforms) u = a.uniforms[(long)ngen * a.uniforms_stride + b];
-    else u = (float)(splitmix64(a.seed ^ ((unsigned long long)ngen << 24) ^ (unsigned long long)b) >> 40) *
-             (1.0f / 16777216.0f);
-    // inverse CDF over the fp32 running sum in index order (torch.cumsum order): first i with c[i] > u * total
-    float total = 0.f;
-    int first = -1, last = 0;
-    for (int n = 0; n < AR_LOGITS; ++n) {
-      const float p = lg[n];
-      if (p > 0.f) { total += p; if (first < 0) first = n; last = n; }
-    }
-    const float thresh = u * total;
-    float c = 0.f;
-    int tok = last;
-    for (int n = first; n <= last; ++n) {
-      const float p = lg[n];
-      if (p > 0.f) { c += p; if (c > thresh) { tok = n; break; } }
-    }
+  if (lane == 0) {
     if (a.force_eos_at >= 0 && ngen >= a.force_eos_at) tok = EOS_ID;
     // stop test: EOS, or (y_len - prompt_len) > 16 * text_len  (models/vallex.py:575-578; y has BOS: 1 + ngen)
     if (tok == EOS_ID || (1 + ngen) > 16 * a.text_len[b] || ngen >= a.gen_stride) {
@@ -525,7 +715,7 @@ __global__ __launch_bounds__(256) void dec_sample_kernel(SampleArgs a) {
 }
 
 void launch_dec_sample(const SampleArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(dec_sample_kernel, dim3(a.batch), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(dec_sample_kernel, dim3(a.batch), dim3(64), 0, s, a);
 }
 
 // teacher forcing (tests): commit a caller-chosen token exactly like dec_sample would

@@ -36,7 +36,7 @@ struct ProfClass {
   double bytes = 0;
 };
 
-constexpr int SK_QKV = 4, SK_OUT = 4, SK_L1 = 4, SK_L2 = 8, SK_PRED = 4;
+constexpr int SK_QKV = 4, SK_OUT = 4, SK_L2 = 8, SK_PRED = 4;
 constexpr int PRED_NPAD = 1056;
 
 }  // namespace
@@ -76,7 +76,7 @@ struct vx_ctx {
   // decode arena
   float *kc = nullptr, *vc = nullptr;      // [NL][mbr*16][Tmax][64]
   float *dh = nullptr, *xp = nullptr, *xp_att = nullptr, *xp4 = nullptr;
-  float *p_qkv = nullptr, *p_o = nullptr, *p_f = nullptr, *p_logits = nullptr, *part_o = nullptr, *part_ml = nullptr;
+  float *p_qkv = nullptr, *p_o = nullptr, *p_logits = nullptr, *part_o = nullptr, *part_ml = nullptr;
   float *d_logits = nullptr, *d_uniforms = nullptr;
   long uniforms_cap = 0;
   int *cur_tok = nullptr, *cur_pos = nullptr, *ctx_len = nullptr, *n_gen = nullptr, *active = nullptr,
@@ -94,7 +94,7 @@ struct vx_ctx {
   std::map<std::string, Tensor> taps;
 
   // profiling / stats
-  bool prof_on = false;
+  int prof_on = 0;                 // 0 off, 1 every class (AR step runs eagerly), 2 full-sequence classes only
   ProfClass prof[4];
   int64_t st_steps = 0, st_frames = 0;
   double st_ar_ms = 0, st_nar_ms = 0;
@@ -146,7 +146,7 @@ struct ProfScope {
   vx_ctx* c;
   int which;
   bool on;
-  ProfScope(vx_ctx* c_, int w) : c(c_), which(w), on(c_->prof_on) {
+  ProfScope(vx_ctx* c_, int w) : c(c_), which(w), on(c_->prof_on == 1 || (c_->prof_on == 2 && w >= 2)) {
     if (!on) return;
     ProfClass& p = c->prof[which];
     if (p.used + 2 > p.ev.size()) {
@@ -301,8 +301,8 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb) {
   HIPCHK(hipMemcpyAsync(c->active, mb.dev(o_1), ib, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->text_len, mb.dev(o_sS), ib, hipMemcpyDeviceToDevice, c->stream));
   c->cur_batch = nb;
-  // enough (row, head, split) blocks to fill 256 CUs a few times over
-  c->nsplit = std::max(1, std::min(16, 1024 / (nb * N_HEAD)));
+  // enough (row, head, split) 8-wave workgroups to put >= 2 on every CU; one split (no combine launch) from 32 rows up
+  c->nsplit = std::max(1, std::min(16, 512 / (nb * N_HEAD)));
 
   launch_embed_rows(c->fx, mb.dev(o_dt), W(c, "ar_text_embedding.word_embeddings.weight"), mb.dev(o_it),
                     W(c, "ar_language_embedding.word_embeddings.weight"), mb.dev(o_lt), W(c, "ar_text_position.alpha"),
@@ -369,8 +369,7 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
     if (c->nsplit > 1) launch_dec_attn_combine(c->part_o, c->part_ml, c->nsplit, c->active, c->xp_att, nb, st);
     { ProfScope ps(c, 1); launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, st); }
     launch_dec_reduce_ln_pack(c->p_o, SK_OUT, D_MODEL, L.out_b, c->dh, c->dh, L.n2_w, L.n2_b, c->xp, nb, st);
-    { ProfScope ps(c, 1); launch_skinny_gemm(L.l1_wp, c->xp, c->p_f, D_FF, D_MODEL, SK_L1, st); }
-    launch_dec_reduce_relu_pack(c->p_f, SK_L1, L.l1_b, c->xp4, nb, st);
+    { ProfScope ps(c, 1); launch_skinny16_relu_pack(L.l1_wp, c->xp, L.l1_b, c->xp4, D_FF, D_MODEL, st); }
     { ProfScope ps(c, 1); launch_skinny_gemm(L.l2_wp, c->xp4, c->p_o, D_MODEL, D_FF, SK_L2, st); }
     const float* ng = (l + 1 < NL) ? c->ar[l + 1].n1_w : W(c, "ar_decoder.norm.weight");
     const float* nbp = (l + 1 < NL) ? c->ar[l + 1].n1_b : W(c, "ar_decoder.norm.bias");
@@ -381,7 +380,7 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
 }
 
 int ar_step_run(vx_ctx* c, const SampleArgs* sa, const std::string& sig) {
-  if (!c->cfg.use_graph || c->prof_on || !sa) {
+  if (!c->cfg.use_graph || c->prof_on == 1 || !sa) {
     ar_step_launches(c, sa);
     HIPCHK(hipGetLastError());
     return VX_OK;
@@ -713,10 +712,9 @@ int vx_finalize_weights(vx_ctx* c) {
   if ((e = dev_alloc(c, &c->dh, (size_t)MB * d))) return e;
   if ((e = dev_alloc(c, &c->xp, (size_t)MB * d))) return e;
   if ((e = dev_alloc(c, &c->xp_att, (size_t)MB * d))) return e;
-  if ((e = dev_alloc(c, &c->xp4, (size_t)MB * f))) return e;
+  if ((e = dev_alloc(c, &c->xp4, (size_t)2 * MB * f))) return e;   // linear1's two split-K slabs, packed image
   if ((e = dev_alloc(c, &c->p_qkv, (size_t)SK_QKV * MB * 3 * d))) return e;
   if ((e = dev_alloc(c, &c->p_o, (size_t)std::max(SK_OUT, SK_L2) * MB * d))) return e;
-  if ((e = dev_alloc(c, &c->p_f, (size_t)SK_L1 * MB * f))) return e;
   if ((e = dev_alloc(c, &c->p_logits, (size_t)SK_PRED * MB * PRED_NPAD))) return e;
   if ((e = dev_alloc(c, &c->part_o, (size_t)MB * N_HEAD * 16 * D_HEAD))) return e;
   if ((e = dev_alloc(c, &c->part_ml, (size_t)MB * N_HEAD * 16 * 2))) return e;
@@ -754,7 +752,8 @@ int vx_finalize_weights(vx_ctx* c) {
     LayerW& L = c->ar[l];
     if ((e = pack(c, L.in_w, 3 * d, d, 3 * d, &L.in_wp))) return e;
     if ((e = pack(c, L.out_w, d, d, d, &L.out_wp))) return e;
-    if ((e = pack(c, L.l1_w, f, d, f, &L.l1_wp))) return e;
+    if ((e = dev_alloc(c, &L.l1_wp, (size_t)f * d, false))) return e;       // 16-row tile image (fused linear1)
+    launch_pack_weight16(L.l1_w, f, d, L.l1_wp, c->stream);
     if ((e = pack(c, L.l2_w, d, f, d, &L.l2_wp))) return e;
   }
   if ((e = pack(c, W(c, "ar_predict_layer.weight"), AR_LOGITS, d, PRED_NPAD, &c->pred_wp))) return e;
@@ -1039,7 +1038,7 @@ int64_t vx_read_tap(vx_ctx* c, const char* name, float* dst, int64_t max_floats)
 
 int vx_prof_enable(vx_ctx* c, int32_t on) {
   if (!c) return VX_EINVAL;
-  c->prof_on = on != 0;
+  c->prof_on = on;
   return VX_OK;
 }
 
@@ -1063,6 +1062,67 @@ int vx_prof_get(vx_ctx* c, int32_t which, double* total_ms, int64_t* launches, d
   if (total_ms) *total_ms = tot;
   if (launches) *launches = (int64_t)(p.used / 2);
   if (algo_bytes) *algo_bytes = p.bytes;
+  return VX_OK;
+}
+
+// Back-to-back replays of ONE decode kernel on the live state of the last AR run, bracketed by a single HIP event
+// pair on the engine stream (GPU-bound: no host gaps inside the interval).  which 0: dec_attn of layer 0 with every
+// row's context set to prefill_len + gen_offset; which 1: the five weight-streaming GEMMs of a step's layer 0
+// (+ predict layer), reported per launch.
+int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, double* avg_us, double* algo_bytes) {
+  if (!c || reps <= 0 || !avg_us || !algo_bytes) return VX_EINVAL;
+  if (c->cur_batch <= 0) FAIL(VX_ESTATE, "no AR run to replay");
+  HIPCHK(hipSetDevice(c->dev));
+  const int nb = c->cur_batch;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  double bytes = 0;
+  int launches = 0;
+  if (which == 0) {
+    std::vector<int> ctx(nb), one(nb, 1);
+    for (int i = 0; i < nb; ++i) {
+      ctx[i] = std::min(c->h_L[i] + std::max(gen_offset, 1), c->Tmax - 1);
+      bytes += (double)ctx[i] * 2.0 * D_MODEL * 4.0;
+    }
+    HIPCHK(hipMemcpyAsync(c->ctx_len, ctx.data(), nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->active, one.data(), nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const LayerW& L = c->ar[0];
+    for (int w = 0; w < 3; ++w)
+      launch_dec_attn(c->p_qkv, SK_QKV, L.in_b, c->kc, c->vc, c->Tmax, c->ctx_len, c->active, c->xp_att, c->part_o,
+                      c->part_ml, c->nsplit, nb, c->stream);
+    HIPCHK(hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; ++r)
+      launch_dec_attn(c->p_qkv, SK_QKV, L.in_b, c->kc, c->vc, c->Tmax, c->ctx_len, c->active, c->xp_att, c->part_o,
+                      c->part_ml, c->nsplit, nb, c->stream);
+    HIPCHK(hipEventRecord(e1, c->stream));
+    launches = reps;
+  } else if (which == 1) {
+    const LayerW& L = c->ar[0];
+    auto seq = [&]() {
+      launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, c->stream);
+      launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, c->stream);
+      launch_skinny16_relu_pack(L.l1_wp, c->xp, L.l1_b, c->xp4, D_FF, D_MODEL, c->stream);
+      launch_skinny_gemm(L.l2_wp, c->xp4, c->p_o, D_MODEL, D_FF, SK_L2, c->stream);
+    };
+    seq();
+    HIPCHK(hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; ++r) seq();
+    HIPCHK(hipEventRecord(e1, c->stream));
+    launches = reps * 4;
+    bytes = 12.0 * D_MODEL * D_MODEL * 4.0 / 4.0;     // per launch: a layer's 12 d^2 weights over its 4 GEMMs
+  } else {
+    FAIL(VX_EINVAL, "which must be 0 or 1");
+  }
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_us = (double)ms * 1e3 / launches;
+  *algo_bytes = bytes;
+  HIPCHK(hipGetLastError());
   return VX_OK;
 }
 

@@ -78,9 +78,16 @@ void launch_skinny_gemm(const float* Wp, const float* xp, float* partial, int Np
 // h[b] = (resid? resid[b] : 0) + sum_ks partial[ks][b] + bias ; xp = pack(LN(h)*g+b)   (N = 1024)
 void launch_dec_reduce_ln_pack(const float* partial, int splitk, int npad, const float* bias, const float* resid,
                                float* h, const float* g, const float* b, float* xp, int batch, hipStream_t s);
-// xp(K=4096) = pack(relu(sum_ks partial + bias))
-void launch_dec_reduce_relu_pack(const float* partial, int splitk, const float* bias, float* xp, int batch,
-                                 hipStream_t s);
+// linear1 with fused bias+ReLU+pack on 16-row tiles (v_mfma_f32_16x16x4_f32), 256 workgroups, no split-K
+void launch_pack_weight16(const float* W, int N, int K, float* Wp, hipStream_t s);
+void launch_skinny16_relu_pack(const float* W16, const float* xp, const float* bias, float* xp_out, int N, int K,
+                               hipStream_t s);
+// linear1: raw split-K partials written directly in linear2's packed-x image  out_pk[ks][32 * Npad]
+void launch_skinny_gemm_packed_out(const float* Wp, const float* xp, float* out_pk, int Npad, int K, int splitk,
+                                   hipStream_t s);
+// linear2: operand x = relu(x_pk[0] + x_pk[1] + xbias) formed while loading (xslab = floats between the two slabs)
+void launch_skinny_gemm_relu_in(const float* Wp, const float* x_pk, const float* xbias, long xslab, float* partial,
+                                int Npad, int K, int splitk, hipStream_t s);
 // h[b] = tab[tok[b]] + alpha*pe[pos[b]] ; xp = pack(LN(h))  -- start of a decode step
 void launch_dec_embed_ln_pack(const int* tok, const int* pos, const float* tab, const float* alpha, const float* pe,
                               float* h, const float* g, const float* b, float* xp, int batch, hipStream_t s);
