@@ -84,6 +84,11 @@ typedef struct vx_sampling {
                                    model's termination; -1 = off) */
   int32_t sync_every;           /* host polls the device EOS flags every n steps (reference: every step,
                                    models/vallex.py:574-578); <= 0 -> 8 */
+  int32_t best_of;              /* <= 1: off.  N > 1 (batch must be 1): N beams of the one utterance sampled independently,
+                                   the beam with the best sum(logp)/len^length_penalty goes on to the NAR stages
+                                   (models/vallex.py:525-527,572,583-594); uniforms, if given, are [steps][best_of] */
+  float length_penalty;         /* models/vallex.py:584 */
+  int32_t return_worst;         /* models/vallex.py:590-591 */
 } vx_sampling;
 
 /* ---- the hot path ---------------------------------------------------------------------------------------- */

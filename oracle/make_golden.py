@@ -53,6 +53,11 @@ CASES = {
     # 2-layer, unfiltered multinomial (API default top_k=-100) with injected uniforms, temperature 0.8
     "nl2_full_multinomial": dict(num_layers=2, seed=4, eos_gain=1.0, synth_prompt=(30, 10), n_text=10, lang="en",
                                  prompt_lang="en", top_k=-100, temperature=0.8, force_eos_at=32, useed=77),
+    # best_of=3 beams (UI path, launch-ui.py:294 uses 5): top-k sampling, natural EOS at different lengths per beam
+    "nl2_bestof3": dict(num_layers=2, seed=5, eos_gain=1.6, preset="paimon", n_text=10, lang="en", top_k=10,
+                        force_eos_at=60, useed=4321, best_of=3),
+    "nl2_bestof3_worst": dict(num_layers=2, seed=5, eos_gain=1.6, preset="paimon", n_text=10, lang="en", top_k=10,
+                              force_eos_at=60, useed=4321, best_of=3, length_penalty=0.7, return_worst=True),
     # full 12-layer model, BASELINE config-1 shape cut to 24 frames (keeps the fixture cheap to re-verify)
     "nl12_c1_short": dict(num_layers=12, seed=0, eos_gain=1.0, preset="librispeech_1", n_text=100, lang="en",
                           top_k=1, force_eos_at=24, useed=None),
@@ -97,7 +102,8 @@ def run_reference(c):
     rec = {"logits": [], "step": 0}
     orig_sampling = V.topk_sampling
     orig_multinomial = torch.multinomial
-    us = None if c["useed"] is None else synth.uniforms(4096, 1, c["useed"])[:, 0]
+    nbeam = c.get("best_of", 1)
+    us = None if c["useed"] is None else synth.uniforms(4096, nbeam, c["useed"])
 
     def hooked(logits, top_k=10, top_p=1.0, temperature=1.0):
         if rec["step"] < 8:
@@ -111,7 +117,8 @@ def run_reference(c):
     def multinomial(probs, num_samples=1, **kw):
         if us is None:
             return orig_multinomial(probs, num_samples, **kw)
-        return torch.tensor([[inverse_cdf_sample(probs[0], float(us[rec["step"]]))]], dtype=torch.long)
+        return torch.tensor([[inverse_cdf_sample(probs[i], float(us[rec["step"], i]))] for i in range(probs.shape[0])],
+                            dtype=torch.long)
 
     nar_logits = []
     orig_nar_pred = m.nar_predict_layers[0].forward
@@ -129,7 +136,8 @@ def run_reference(c):
             codes = m.inference(torch.from_numpy(text).to(torch.int32), torch.IntTensor([text.shape[-1]]),
                                 torch.from_numpy(a).to(torch.int32), enroll_x_lens=t.shape[-1],
                                 top_k=c["top_k"], temperature=c.get("temperature", 1.0),
-                                prompt_language=pl, text_language=langs)
+                                prompt_language=pl, text_language=langs, best_of=nbeam,
+                                length_penalty=c.get("length_penalty", 1.0), return_worst=c.get("return_worst", False))
     finally:
         V.topk_sampling = orig_sampling
         torch.multinomial = orig_multinomial

@@ -218,7 +218,7 @@ class VallexOracle:
 
     def ar_generate(self, text, prompt_codes0, enroll, prompt_language, text_language, top_k=-100,
                     temperature=1.0, uniforms: Optional[Sequence[float]] = None,
-                    force_eos_at: Optional[int] = None, taps=None) -> List[int]:
+                    force_eos_at: Optional[int] = None, taps=None, return_logp: bool = False):
         """models/vallex.py:528-598 for best_of=1.  `force_eos_at=n` forces EOS as the
         (n+1)-th sample (the reference-side equivalent is the topk_sampling hook in
         oracle/make_golden.py) so synthetic weights can emulate an 8 s utterance."""
@@ -227,12 +227,14 @@ class VallexOracle:
         y_len = Tp + 1
         gen: List[int] = []
         step = 0
+        sum_logp = np.float32(0.0)
         while True:
             logits = self.ar_logits(h)
             if taps is not None:
                 taps.setdefault("ar_logits", []).append(logits.clone())
             u = None if uniforms is None else float(uniforms[step])
-            tok, _ = self.sample(logits, top_k, temperature, u)
+            tok, lp = self.sample(logits, top_k, temperature, u)
+            sum_logp = np.float32(sum_logp + np.float32(lp))                 # :572 (beam not finished yet)
             if force_eos_at is not None and step >= force_eos_at:
                 tok = synth.EOS_ID
             if tok == synth.EOS_ID or (y_len - Tp) > S * 16:               # :575-578
@@ -244,7 +246,7 @@ class VallexOracle:
             y_len += 1
             h, kv = self.ar_step(tok, y_len - 1, kv)
             step += 1
-        return gen
+        return (gen, float(sum_logp)) if return_logp else gen
 
     # ---- NAR (models/vallex.py:600-686, prefix_mode 1) ----------------------
     def nar_generate(self, text, prompts, codes0: Sequence[int], enroll, prompt_language, text_language,
@@ -276,13 +278,27 @@ class VallexOracle:
 
     # ---- VALLE.inference (models/vallex.py:458-686) -------------------------
     def inference(self, x, x_lens, y, enroll_x_lens, top_k=-100, temperature=1.0, prompt_language=None,
-                  text_language=None, uniforms=None, force_eos_at=None, taps=None) -> np.ndarray:
+                  text_language=None, uniforms=None, force_eos_at=None, taps=None, best_of=1, length_penalty=1.0,
+                  return_worst=False) -> np.ndarray:
         x = np.asarray(x); y = np.asarray(y)
         assert x.ndim == 2 and y.ndim == 3 and y.shape[0] == 1            # :488-493
         text = torch.from_numpy(x[0].astype(np.int64))
         prompts = torch.from_numpy(y[0].astype(np.int64))
-        gen = self.ar_generate(text, prompts[:, 0], int(enroll_x_lens), prompt_language, text_language,
-                               top_k, temperature, uniforms, force_eos_at, taps)
+        if best_of > 1:
+            # beams never interact (models/vallex.py:525-598 runs them as batch rows): N independent samplings with
+            # their own uniform column, then the :583-594 selection on sum(logp) / len^penalty, len = #non-EOS of y
+            us = np.asarray(uniforms, np.float32).reshape(-1, best_of)
+            beams = [self.ar_generate(text, prompts[:, 0], int(enroll_x_lens), prompt_language, text_language, top_k,
+                                      temperature, us[:, i], force_eos_at, None, return_logp=True) for i in range(best_of)]
+            lengths = torch.tensor([1 + prompts.shape[0] + len(g) for g, _ in beams])
+            avg = torch.tensor([lp for _, lp in beams], dtype=torch.float32) / lengths ** length_penalty
+            pick = int(torch.argmin(avg)) if return_worst else int(torch.argmax(avg))
+            gen = beams[pick][0]
+            if taps is not None:
+                taps["beam_avg_logprobs"] = avg.numpy()
+        else:
+            gen = self.ar_generate(text, prompts[:, 0], int(enroll_x_lens), prompt_language, text_language,
+                                   top_k, temperature, uniforms, force_eos_at, taps)
         codes = self.nar_generate(text, prompts, gen, int(enroll_x_lens), prompt_language, text_language, taps)
         return codes[None]                                                   # (1, T, 8) int64
 

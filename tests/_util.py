@@ -40,7 +40,10 @@ def case_row(name):
     c = CASES[name]
     a, t, text, pl, langs = case_inputs(c)
     row = dict(text=text[0], prompt=a[0], enroll=t.shape[-1], prompt_language=pl, text_language=langs)
-    us = None if c["useed"] is None else synth.uniforms(4096, 1, c["useed"])[:, 0]
+    nb = c.get("best_of", 1)
+    us = None if c["useed"] is None else synth.uniforms(4096, nb, c["useed"])
+    if us is not None and nb == 1:
+        us = us[:, 0]
     return c, row, us
 
 

@@ -32,7 +32,7 @@ def test_struct_layout_matches_header():
     from vallex_amd._capi import vx_batch, vx_config, vx_sampling
     assert C.sizeof(vx_config) == 8 * 4
     assert vx_batch.text_lens.offset == 32 and C.sizeof(vx_batch) == 64
-    assert vx_sampling.seed.offset == 24 and C.sizeof(vx_sampling) == 40
+    assert vx_sampling.seed.offset == 24 and vx_sampling.best_of.offset == 40 and C.sizeof(vx_sampling) == 56
 
 
 def test_fails_loudly_without_gpu(lib):

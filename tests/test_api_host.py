@@ -63,8 +63,6 @@ def test_inference_asserts_like_reference():
         m.inference(x, np.array([5]), np.zeros((2, 4, 8), np.int32), 2, prompt_language="en", text_language="en")
     with pytest.raises(AssertionError):
         m.inference(x, np.array([0]), y, 2, prompt_language="en", text_language="en")           # x_lens > 0
-    with pytest.raises(NotImplementedError):
-        m.inference(x, np.array([5]), y, 2, prompt_language="en", text_language="en", best_of=5)
 
 
 def test_language_rows_and_model_ids():

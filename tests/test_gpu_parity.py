@@ -69,7 +69,9 @@ def test_infer_matches_reference_tokens(name):
     m = get_model(c["num_layers"], c["seed"], c["eos_gain"])
     out = m.inference(row["text"][None], np.array([len(row["text"])]), row["prompt"][None], row["enroll"],
                       top_k=c["top_k"], temperature=c.get("temperature", 1.0), prompt_language=row["prompt_language"],
-                      text_language=row["text_language"], uniforms=us, force_eos_at=c["force_eos_at"])
+                      text_language=row["text_language"], uniforms=us, force_eos_at=c["force_eos_at"],
+                      best_of=c.get("best_of", 1), length_penalty=c.get("length_penalty", 1.0),
+                      return_worst=c.get("return_worst", False))
     g = golden(name)["codes"]
     assert tuple(out.shape) == g.shape
     np.testing.assert_array_equal(out.numpy(), g)
@@ -163,3 +165,36 @@ def test_generate_audio_api_end_to_end():
     wav2 = G.generate_audio_from_long_text([ids, synth.synth_text(9, 4)], prompt=preset, language="en",
                                            mode="fixed-prompt", uniforms=us, force_eos_at=10)
     assert wav2.shape[0] == 2 * 10 * 320 and np.isfinite(wav2).all()
+
+
+def test_long_text_sliding_window_carries_prompt():
+    """generate_audio_from_long_text(mode='sliding-window') with the carry branch always taken (launch-ui.py:493
+    behaviour): chunk k+1 is prompted by ALL frames and the text ids of chunk k (utils/generation.py:264-266)."""
+    import os
+    from vallex_amd.utils import generation as G
+    sd = synth.vallex_state_dict(2, 11)
+    vsd = synth.vocos_state_dict(2)
+    G.preload_models(state_dict=sd, vocos_state_dict=vsd, num_layers=2, max_new=320, max_prompt=400, max_text=256,
+                     max_batch=4)
+    preset = os.path.join(os.path.dirname(__file__), "golden", "presets", "paimon.npz")
+    s1, s2 = synth.synth_text(9, 21), synth.synth_text(7, 22)
+
+    class Always:
+        def random(self):
+            return 0.0
+    G.rng = Always()
+    # generate_audio* fix top_k=-100 like the reference; make the draw deterministic with injected uniforms instead
+    us = synth.uniforms(64, 1, 5)[:, 0]
+    wav = G.generate_audio_from_long_text([s1, s2], prompt=preset, language="en", mode="sliding-window", uniforms=us,
+                                          force_eos_at=12)
+    d = np.load(preset)
+    orc = VallexOracle(sd, 2)
+    t1 = np.concatenate([d["text_tokens"][0], s1])[None]
+    c1 = orc.inference(t1, np.array([t1.shape[1]]), d["audio_tokens"], d["text_tokens"].shape[1], top_k=-100,
+                       prompt_language="zh", text_language="en", uniforms=us, force_eos_at=12)
+    t2 = np.concatenate([s1, s2])[None]
+    c2 = orc.inference(t2, np.array([t2.shape[1]]), c1, len(s1), top_k=-100, prompt_language="zh", text_language="en",
+                       uniforms=us, force_eos_at=12)
+    ref = VocosOracle(vsd).decode_codes(np.concatenate([c1, c2], axis=1), 2)[0]
+    assert wav.shape == ref.shape
+    assert float(np.sqrt(np.mean((wav - ref) ** 2))) <= 1e-4

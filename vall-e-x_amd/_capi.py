@@ -39,7 +39,8 @@ class vx_batch(C.Structure):
 class vx_sampling(C.Structure):
     _fields_ = [("top_k", C.c_int32), ("temperature", C.c_float), ("uniforms", C.POINTER(C.c_float)),
                 ("uniforms_steps", C.c_int32), ("seed", C.c_uint64), ("force_eos_at", C.c_int32),
-                ("sync_every", C.c_int32)]
+                ("sync_every", C.c_int32), ("best_of", C.c_int32), ("length_penalty", C.c_float),
+                ("return_worst", C.c_int32)]
 
 
 # every symbol include/vallex_hip.h declares (tests/test_abi.py checks the library exports exactly these)
@@ -166,10 +167,13 @@ class Engine:
         self._chk(self.lib.vx_synchronize(self.ctx))
 
     @staticmethod
-    def _sampling(n, top_k, temperature, uniforms, seed, force_eos_at, sync_every):
+    def _sampling(n, top_k, temperature, uniforms, seed, force_eos_at, sync_every, best_of=1, length_penalty=1.0,
+                  return_worst=False):
         u = None
         s = vx_sampling(int(top_k), float(temperature), None, 0, int(seed), -1 if force_eos_at is None else int(force_eos_at),
-                        int(sync_every))
+                        int(sync_every), int(best_of), float(length_penalty), int(bool(return_worst)))
+        if best_of > 1:
+            n = int(best_of)
         if uniforms is not None:
             u = np.ascontiguousarray(uniforms, np.float32)
             if u.ndim == 1:
@@ -180,8 +184,9 @@ class Engine:
         return s, u
 
     def infer(self, batch: Batch, top_k=-100, temperature=1.0, uniforms=None, seed=0, force_eos_at=None,
-              sync_every=8):
-        s, _keep = self._sampling(batch.n, top_k, temperature, uniforms, seed, force_eos_at, sync_every)
+              sync_every=8, best_of=1, length_penalty=1.0, return_worst=False):
+        s, _keep = self._sampling(batch.n, top_k, temperature, uniforms, seed, force_eos_at, sync_every, best_of,
+                                  length_penalty, return_worst)
         out = np.zeros((batch.n, self.max_new, 8), np.int64)
         lens = np.zeros(batch.n, np.int32)
         self._chk(self.lib.vx_infer(self.ctx, C.byref(batch.c), C.byref(s), _ptr(out, C.c_int64), self.max_new,

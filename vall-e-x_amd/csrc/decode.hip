@@ -59,8 +59,10 @@ void launch_pack_weight(const float* W, int N, int K, float* Wp, int Npad, hipSt
 template <int OUT, int XIN>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restrict__ Wp, const float* __restrict__ xp,
                                                           float* __restrict__ out, const float* __restrict__ xbias,
-                                                          long xslab, int Npad, int K, int splitk) {
+                                                          long xslab, int Npad, int K, int splitk,
+                                                          const int* __restrict__ n_active) {
   __shared__ __attribute__((aligned(16))) float red[3 * 16 * 64];
+  if (n_active && *n_active == 0) return;          // every row has finished: the rest of this step is a no-op
   const int nt = blockIdx.x, ks = blockIdx.y;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int KB = K / 8;
@@ -125,23 +127,9 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
 }
 
 void launch_skinny_gemm(const float* Wp, const float* xp, float* partial, int Npad, int K, int splitk,
-                        hipStream_t s) {
+                        const int* n_active, hipStream_t s) {
   hipLaunchKernelGGL((skinny_gemm_kernel<0, 0>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, xp, partial, nullptr,
-                     0L, Npad, K, splitk);
-}
-
-// linear1: raw split-K(2) partials written directly in linear2's packed-x image
-void launch_skinny_gemm_packed_out(const float* Wp, const float* xp, float* out_pk, int Npad, int K, int splitk,
-                                   hipStream_t s) {
-  hipLaunchKernelGGL((skinny_gemm_kernel<1, 0>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, xp, out_pk, nullptr, 0L,
-                     Npad, K, splitk);
-}
-
-// linear2: x = relu(pk[0] + pk[1] + bias1) formed while loading the operand
-void launch_skinny_gemm_relu_in(const float* Wp, const float* x_pk, const float* xbias, long xslab, float* partial,
-                                int Npad, int K, int splitk, hipStream_t s) {
-  hipLaunchKernelGGL((skinny_gemm_kernel<0, 1>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, x_pk, partial, xbias,
-                     xslab, Npad, K, splitk);
+                     0L, Npad, K, splitk, n_active);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -175,8 +163,10 @@ constexpr int S16_WAVES = 8;
 __global__ __launch_bounds__(S16_WAVES * 64) void skinny16_relu_pack_kernel(const float* __restrict__ W16,
                                                                             const float* __restrict__ xp,
                                                                             const float* __restrict__ bias,
-                                                                            float* __restrict__ xp_out, int K) {
+                                                                            float* __restrict__ xp_out, int K,
+                                                                            const int* __restrict__ n_active) {
   __shared__ __attribute__((aligned(16))) float red[(S16_WAVES - 1) * 8 * 64];
+  if (n_active && *n_active == 0) return;
   const int nt = blockIdx.x;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int KB = K / 16, per = KB / S16_WAVES;        // K = 1024: 64 k-blocks, 8 per wave
@@ -229,8 +219,9 @@ __global__ __launch_bounds__(S16_WAVES * 64) void skinny16_relu_pack_kernel(cons
 }
 
 void launch_skinny16_relu_pack(const float* W16, const float* xp, const float* bias, float* xp_out, int N, int K,
-                               hipStream_t s) {
-  hipLaunchKernelGGL(skinny16_relu_pack_kernel, dim3(N / 16), dim3(S16_WAVES * 64), 0, s, W16, xp, bias, xp_out, K);
+                               const int* n_active, hipStream_t s) {
+  hipLaunchKernelGGL(skinny16_relu_pack_kernel, dim3(N / 16), dim3(S16_WAVES * 64), 0, s, W16, xp, bias, xp_out, K,
+                     n_active);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -699,11 +690,21 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
   for (int o = 32; o > 0; o >>= 1) last_all = max(last_all, __shfl_xor(last_all, o, 64));
   int tok = cand == 0x7fffffff ? last_all : cand;
 
+  // log-prob of the pick under the filtered distribution (F.log_softmax, models/vallex.py:851-852), accumulated per
+  // row for best-of-N beam selection (models/vallex.py:572); the owning lane adds it.
+  if (a.sum_logp && tok / SPL == lane) {
+    float vt = 0.f;
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) if (tok - lane * SPL == j) vt = v[j];
+    a.sum_logp[b] += (vt - mx) - logf(total);
+  }
+
   if (lane == 0) {
     if (a.force_eos_at >= 0 && ngen >= a.force_eos_at) tok = EOS_ID;
     // stop test: EOS, or (y_len - prompt_len) > 16 * text_len  (models/vallex.py:575-578; y has BOS: 1 + ngen)
     if (tok == EOS_ID || (1 + ngen) > 16 * a.text_len[b] || ngen >= a.gen_stride) {
       a.active[b] = 0;
+      if (a.n_active) atomicSub(a.n_active, 1);
     } else {
       a.gen[(long)b * a.gen_stride + ngen] = tok;
       a.n_gen[b] = ngen + 1;

@@ -77,10 +77,10 @@ struct vx_ctx {
   float *kc = nullptr, *vc = nullptr;      // [NL][mbr*16][Tmax][64]
   float *dh = nullptr, *xp = nullptr, *xp_att = nullptr, *xp4 = nullptr;
   float *p_qkv = nullptr, *p_o = nullptr, *p_logits = nullptr, *part_o = nullptr, *part_ml = nullptr;
-  float *d_logits = nullptr, *d_uniforms = nullptr;
+  float *d_logits = nullptr, *d_uniforms = nullptr, *sum_logp = nullptr;
   long uniforms_cap = 0;
   int *cur_tok = nullptr, *cur_pos = nullptr, *ctx_len = nullptr, *n_gen = nullptr, *active = nullptr,
-      *text_len = nullptr, *gen = nullptr, *force_tok = nullptr;
+      *text_len = nullptr, *gen = nullptr, *force_tok = nullptr, *n_active = nullptr;
   int gen_stride = 0;
   int cur_batch = 0;
   int nsplit = 1;
@@ -300,6 +300,7 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb) {
   HIPCHK(hipMemcpyAsync(c->cur_tok, mb.dev(o_z), ib, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->active, mb.dev(o_1), ib, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->text_len, mb.dev(o_sS), ib, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->n_active, &nb, sizeof(int), hipMemcpyHostToDevice, c->stream));
   c->cur_batch = nb;
   // enough (row, head, split) 8-wave workgroups to put >= 2 on every CU; one split (no combine launch) from 32 rows up
   c->nsplit = std::max(1, std::min(16, 512 / (nb * N_HEAD)));
@@ -331,7 +332,7 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb) {
   // final norm + ar_predict_layer on those rows (models/vallex.py:568)
   launch_dec_reduce_ln_pack(nullptr, 0, D_MODEL, nullptr, c->dh, nullptr, W(c, "ar_decoder.norm.weight"),
                             W(c, "ar_decoder.norm.bias"), c->xp, nb, c->stream);
-  launch_skinny_gemm(c->pred_wp, c->xp, c->p_logits, PRED_NPAD, D_MODEL, SK_PRED, c->stream);
+  launch_skinny_gemm(c->pred_wp, c->xp, c->p_logits, PRED_NPAD, D_MODEL, SK_PRED, nullptr, c->stream);
   return VX_OK;
 }
 
@@ -346,7 +347,9 @@ SampleArgs make_sample_args(vx_ctx* c, const vx_sampling* s, int commit, float* 
   a.force_eos_at = s ? s->force_eos_at : -1;
   a.commit = commit;
   a.cur_tok = c->cur_tok; a.cur_pos = c->cur_pos; a.ctx_len = c->ctx_len; a.n_gen = c->n_gen; a.active = c->active;
+  a.n_active = c->n_active;
   a.text_len = c->text_len; a.gen = c->gen; a.gen_stride = c->gen_stride; a.logits_out = logits_out;
+  a.sum_logp = (s && s->best_of > 1) ? c->sum_logp : nullptr;
   a.batch = c->cur_batch;
   return a;
 }
@@ -360,22 +363,22 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
                            W(c, "ar_audio_position.alpha"), c->pe, c->dh, c->ar[0].n1_w, c->ar[0].n1_b, c->xp, nb, st);
   for (int l = 0; l < NL; ++l) {
     const LayerW& L = c->ar[l];
-    { ProfScope ps(c, 1); launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, st); }
+    { ProfScope ps(c, 1); launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, c->n_active, st); }
     {
       ProfScope ps(c, 0);
       launch_dec_attn(c->p_qkv, SK_QKV, L.in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax, c->ctx_len,
                       c->active, c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, st);
     }
     if (c->nsplit > 1) launch_dec_attn_combine(c->part_o, c->part_ml, c->nsplit, c->active, c->xp_att, nb, st);
-    { ProfScope ps(c, 1); launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, st); }
+    { ProfScope ps(c, 1); launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, c->n_active, st); }
     launch_dec_reduce_ln_pack(c->p_o, SK_OUT, D_MODEL, L.out_b, c->dh, c->dh, L.n2_w, L.n2_b, c->xp, nb, st);
-    { ProfScope ps(c, 1); launch_skinny16_relu_pack(L.l1_wp, c->xp, L.l1_b, c->xp4, D_FF, D_MODEL, st); }
-    { ProfScope ps(c, 1); launch_skinny_gemm(L.l2_wp, c->xp4, c->p_o, D_MODEL, D_FF, SK_L2, st); }
+    { ProfScope ps(c, 1); launch_skinny16_relu_pack(L.l1_wp, c->xp, L.l1_b, c->xp4, D_FF, D_MODEL, c->n_active, st); }
+    { ProfScope ps(c, 1); launch_skinny_gemm(L.l2_wp, c->xp4, c->p_o, D_MODEL, D_FF, SK_L2, c->n_active, st); }
     const float* ng = (l + 1 < NL) ? c->ar[l + 1].n1_w : W(c, "ar_decoder.norm.weight");
     const float* nbp = (l + 1 < NL) ? c->ar[l + 1].n1_b : W(c, "ar_decoder.norm.bias");
     launch_dec_reduce_ln_pack(c->p_o, SK_L2, D_MODEL, L.l2_b, c->dh, c->dh, ng, nbp, c->xp, nb, st);
   }
-  { ProfScope ps(c, 1); launch_skinny_gemm(c->pred_wp, c->xp, c->p_logits, PRED_NPAD, D_MODEL, SK_PRED, st); }
+  { ProfScope ps(c, 1); launch_skinny_gemm(c->pred_wp, c->xp, c->p_logits, PRED_NPAD, D_MODEL, SK_PRED, c->n_active, st); }
   if (sa) launch_dec_sample(*sa, st);
 }
 
@@ -413,11 +416,12 @@ int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int 
     HIPCHK(hipMemcpyAsync(c->d_uniforms, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
   }
+  HIPCHK(hipMemsetAsync(c->sum_logp, 0, MB * sizeof(float), c->stream));
   SampleArgs sa = make_sample_args(c, s, 1, nullptr);
   launch_dec_sample(sa, c->stream);                                     // first token from the prefill logits
   char sig[160];
-  snprintf(sig, sizeof sig, "b%d ns%d k%d t%a u%d f%d s%llu", nb, c->nsplit, sa.top_k, sa.temperature,
-           sa.uniforms != nullptr, sa.force_eos_at, (unsigned long long)sa.seed);
+  snprintf(sig, sizeof sig, "b%d ns%d k%d t%a u%d f%d s%llu l%d", nb, c->nsplit, sa.top_k, sa.temperature,
+           sa.uniforms != nullptr, sa.force_eos_at, (unsigned long long)sa.seed, sa.sum_logp != nullptr);
   const int sync_every = s->sync_every > 0 ? s->sync_every : 8;
   std::vector<int> act(nb);
   const int hard_cap = c->gen_stride + 2;
@@ -719,9 +723,10 @@ int vx_finalize_weights(vx_ctx* c) {
   if ((e = dev_alloc(c, &c->part_o, (size_t)MB * N_HEAD * 16 * D_HEAD))) return e;
   if ((e = dev_alloc(c, &c->part_ml, (size_t)MB * N_HEAD * 16 * 2))) return e;
   if ((e = dev_alloc(c, &c->d_logits, (size_t)MB * AR_LOGITS))) return e;
+  if ((e = dev_alloc(c, &c->sum_logp, (size_t)MB))) return e;
   c->uniforms_cap = (long)(c->cfg.max_new + 2) * MB;
   if ((e = dev_alloc(c, &c->d_uniforms, (size_t)c->uniforms_cap))) return e;
-  for (int** p : {&c->cur_tok, &c->cur_pos, &c->ctx_len, &c->n_gen, &c->active, &c->text_len, &c->force_tok})
+  for (int** p : {&c->cur_tok, &c->cur_pos, &c->ctx_len, &c->n_gen, &c->active, &c->text_len, &c->force_tok, &c->n_active})
     if ((e = dev_alloc(c, p, MB))) return e;
   if ((e = dev_alloc(c, &c->gen, (size_t)MB * c->gen_stride))) return e;
 
@@ -930,6 +935,47 @@ int vx_infer(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int64_t* out_co
   if (int e = check_batch(c, b, c->cfg.max_batch)) return e;
   if (!(s->temperature > 0.f)) FAIL(VX_EINVAL, "temperature must be > 0");
   c->st_steps = 0; c->st_frames = 0; c->st_ar_ms = 0; c->st_nar_ms = 0;
+  if (s->best_of > 1) {
+    // best-of-N beams of ONE utterance (models/vallex.py:491,525-527): the row is replicated N times, every beam
+    // samples independently, beams that emit EOS stop; selection on sum(logp) / len^penalty (:583-594), then the NAR
+    // stages run on the chosen beam only (:600).
+    if (b->batch != 1) FAIL(VX_EINVAL, "best_of > 1 needs batch == 1 (models/vallex.py:491)");
+    const int N = s->best_of;
+    if (N > c->mbr) FAIL(VX_EINVAL, "best_of %d exceeds the micro-batch (%d)", N, c->mbr);
+    const int S = b->text_lens[0], Tp = b->prompt_lens[0];
+    std::vector<int> ids((size_t)N * S), lg((size_t)N * S), tl(N, S), pc((size_t)N * std::max(Tp, 1) * N_Q, 0), pl(N, Tp);
+    for (int i = 0; i < N; ++i) {
+      memcpy(&ids[(size_t)i * S], b->text_ids, S * sizeof(int));
+      memcpy(&lg[(size_t)i * S], b->text_lang, S * sizeof(int));
+      if (Tp) memcpy(&pc[(size_t)i * Tp * N_Q], b->prompt_codes, (size_t)Tp * N_Q * sizeof(int));
+    }
+    vx_batch rb{N, ids.data(), lg.data(), S, tl.data(), pc.data(), std::max(Tp, 1), pl.data()};
+    std::vector<int> n_gen, gen, oc;
+    if (int e = ar_generate(c, &rb, s, 0, N, n_gen, gen)) return e;
+    std::vector<float> slp(N);
+    HIPCHK(hipMemcpy(slp.data(), c->sum_logp, N * sizeof(float), hipMemcpyDeviceToHost));
+    int best = 0, worst = 0;
+    double bv = 0, wv = 0;
+    for (int i = 0; i < N; ++i) {
+      const double len = 1.0 + Tp + n_gen[i];                        // torch.sum(y != EOS): BOS + prompt + frames
+      const double v = (double)(float)((float)slp[i] / powf((float)len, s->length_penalty));
+      if (i == 0 || v > bv) { bv = v; best = i; }
+      if (i == 0 || v < wv) { wv = v; worst = i; }
+    }
+    const int pick = s->return_worst ? worst : best;
+    if (n_gen[pick] > out_stride) FAIL(VX_EINVAL, "out_stride %d too small for %d frames", out_stride, n_gen[pick]);
+    long sumT = 0;
+    std::vector<int> T1(1, n_gen[pick]);
+    if (int e = nar_generate(c, b, 0, 1, T1, gen.data() + (size_t)pick * c->gen_stride, c->gen_stride, oc, sumT)) return e;
+    out_lens[0] = n_gen[pick];
+    c->st_frames = n_gen[pick];
+    for (int t = 0; t < n_gen[pick]; ++t) {
+      int64_t* o = out_codes + (long)t * N_Q;
+      o[0] = gen[(size_t)pick * c->gen_stride + t];
+      for (int st = 0; st < N_Q - 1; ++st) o[st + 1] = oc[(size_t)st * sumT + t];
+    }
+    return VX_OK;
+  }
   hipEvent_t e0, e1, e2;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
   for (int r0 = 0; r0 < b->batch; r0 += c->mbr) {
@@ -1101,10 +1147,10 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
   } else if (which == 1) {
     const LayerW& L = c->ar[0];
     auto seq = [&]() {
-      launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, c->stream);
-      launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, c->stream);
-      launch_skinny16_relu_pack(L.l1_wp, c->xp, L.l1_b, c->xp4, D_FF, D_MODEL, c->stream);
-      launch_skinny_gemm(L.l2_wp, c->xp4, c->p_o, D_MODEL, D_FF, SK_L2, c->stream);
+      launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, nullptr, c->stream);
+      launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, nullptr, c->stream);
+      launch_skinny16_relu_pack(L.l1_wp, c->xp, L.l1_b, c->xp4, D_FF, D_MODEL, nullptr, c->stream);
+      launch_skinny_gemm(L.l2_wp, c->xp4, c->p_o, D_MODEL, D_FF, SK_L2, nullptr, c->stream);
     };
     seq();
     HIPCHK(hipEventRecord(e0, c->stream));

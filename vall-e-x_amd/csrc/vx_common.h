@@ -74,14 +74,21 @@ void launch_attn_full(const float* qkv, float* out, const int* seq_off, const in
 void launch_pack_weight(const float* W, int N, int K, float* Wp, int Npad, hipStream_t s);
 // partial[ks][b][n] = sum_{k in slice ks} x[b][k] * W[n][k];  xp is the packed activation image.
 void launch_skinny_gemm(const float* Wp, const float* xp, float* partial, int Npad, int K, int splitk,
-                        hipStream_t s);
+                        const int* n_active, hipStream_t s);
 // h[b] = (resid? resid[b] : 0) + sum_ks partial[ks][b] + bias ; xp = pack(LN(h)*g+b)   (N = 1024)
 void launch_dec_reduce_ln_pack(const float* partial, int splitk, int npad, const float* bias, const float* resid,
                                float* h, const float* g, const float* b, float* xp, int batch, hipStream_t s);
 // linear1 with fused bias+ReLU+pack on 16-row tiles (v_mfma_f32_16x16x4_f32), 256 workgroups, no split-K
 void launch_pack_weight16(const float* W, int N, int K, float* Wp, hipStream_t s);
 void launch_skinny16_relu_pack(const float* W16, const float* xp, const float* bias, float* xp_out, int N, int K,
-                               hipStream_t s);
+                               const int* n_active, hipStream_t s);
+// h[b] = (resid? resid[b] : 0) + sum_ks partial[ks][b] + bias ; xp = pack(LN(h)*g+b)   (N = 1024)
+void launch_dec_reduce_ln_pack(const float* partial, int splitk, int npad, const float* bias, const float* resid,
+                               float* h, const float* g, const float* b, float* xp, int batch, hipStream_t s);
+// linear1 with fused bias+ReLU+pack on 16-row tiles (v_mfma_f32_16x16x4_f32), 256 workgroups, no split-K
+void launch_pack_weight16(const float* W, int N, int K, float* Wp, hipStream_t s);
+void launch_skinny16_relu_pack(const float* W16, const float* xp, const float* bias, float* xp_out, int N, int K,
+                               const int* n_active, hipStream_t s);
 // linear1: raw split-K partials written directly in linear2's packed-x image  out_pk[ks][32 * Npad]
 void launch_skinny_gemm_packed_out(const float* Wp, const float* xp, float* out_pk, int Npad, int K, int splitk,
                                    hipStream_t s);
@@ -104,9 +111,10 @@ struct SampleArgs {
   unsigned long long seed;
   int force_eos_at;
   int commit;                                      // 0: only reduce (and export) the logits
-  int* cur_tok; int* cur_pos; int* ctx_len; int* n_gen; int* active; const int* text_len;
+  int* cur_tok; int* cur_pos; int* ctx_len; int* n_gen; int* active; int* n_active; const int* text_len;
   int* gen; int gen_stride;                        // generated ids [b][gen_stride]
   float* logits_out;                               // optional [MB][1025] copy of the reduced logits
+  float* sum_logp;                                 // optional [MB] running sum of log p(pick) per row (beam selection)
   int batch;
 };
 void launch_dec_sample(const SampleArgs& a, hipStream_t s);

@@ -3,8 +3,8 @@ implemented as a thin host shim over the C ABI (include/vallex_hip.h).  No torch
 straight to the GPU engine, tokens come back.
 
 Differences a caller can observe (all documented in DESIGN.md):
-  * `inference` accepts the same arguments and returns the same LongTensor (1, T, 8); `best_of`/`length_penalty`/
-    `return_worst` other than the defaults raise NotImplementedError (SURVEY.md §8f row 2, not built yet);
+  * `inference` accepts the same arguments and returns the same LongTensor (1, T, 8), including `best_of` /
+    `length_penalty` / `return_worst` (beams = rows of the micro-batch, selection on the device-accumulated log-probs);
   * extra, reference-less entry points for what BASELINE.json measures: `inference_batch` (distinct utterances in one
     call; the reference can only batch beams of ONE utterance, models/vallex.py:491,525-527) and the reproducibility
     hooks `uniforms=` / `force_eos_at=` (the reference needs monkey-patching for the same effect).
@@ -179,19 +179,22 @@ class VALLE:
         assert ya.ndim == 3, ya.shape
         assert ya.shape[0] == 1, ya.shape
         assert np.all(xl > 0)
-        if best_of != 1 or length_penalty != 1.0 or return_worst:
-            raise NotImplementedError("best_of>1 beam selection is not built yet (SURVEY.md §8f)")
         S = int(xl.max())
         row = dict(text=xa[0, :S], prompt=ya[0], enroll=int(_np(enroll_x_lens)), prompt_language=prompt_language,
                    text_language=text_language)
-        codes = self.inference_batch([row], top_k=top_k, temperature=temperature,
-                                     uniforms=None if uniforms is None else np.asarray(uniforms, np.float32).reshape(-1, 1),
-                                     force_eos_at=force_eos_at, seed=seed)[0]
+        u = None
+        if uniforms is not None:
+            u = np.asarray(uniforms, np.float32)
+            u = u.reshape(-1, max(1, int(best_of))) if u.ndim == 1 else u
+        codes = self.inference_batch([row], top_k=top_k, temperature=temperature, uniforms=u, force_eos_at=force_eos_at,
+                                     seed=seed, best_of=best_of, length_penalty=length_penalty,
+                                     return_worst=return_worst)[0]
         out = codes[None]
         return torch.from_numpy(out) if torch is not None else out
 
     def inference_batch(self, rows: Sequence[dict], top_k: int = -100, temperature: float = 1.0, uniforms=None,
-                        force_eos_at=None, seed: int = 0, sync_every: int = 8) -> List[np.ndarray]:
+                        force_eos_at=None, seed: int = 0, sync_every: int = 8, best_of: int = 1,
+                        length_penalty: float = 1.0, return_worst: bool = False) -> List[np.ndarray]:
         """rows[i] = dict(text ids (S,), prompt codes (Tp,8), enroll, prompt_language, text_language).
         Row i equals `inference` run alone on that row.  Returns one (T_i, 8) int64 array per row."""
         texts, langs, prompts = [], [], []
@@ -202,7 +205,8 @@ class VALLE:
             prompts.append(p)
             langs.append(self._lang_row(len(t), int(r["enroll"]), r["prompt_language"], r["text_language"]))
         return self.engine.infer(Batch(texts, langs, prompts), top_k=top_k, temperature=temperature, uniforms=uniforms,
-                                 seed=seed, force_eos_at=force_eos_at, sync_every=sync_every)
+                                 seed=seed, force_eos_at=force_eos_at, sync_every=sync_every, best_of=best_of,
+                                 length_penalty=length_penalty, return_worst=return_worst)
 
     def make_batch(self, rows: Sequence[dict]) -> Batch:
         texts = [_np(r["text"], np.int32).reshape(-1) for r in rows]
