@@ -408,7 +408,8 @@ int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int 
   if (int e = ar_prefill(c, b, r0, nb)) return e;
   if (s->uniforms) {
     // slice [steps][batch] -> [steps][nb] for this micro-batch
-    const long steps = s->uniforms_steps;
+    // only the first gen_stride + 1 draws can ever be consumed (one per generated frame + the terminating sample)
+    const long steps = std::min<long>(s->uniforms_steps, c->gen_stride + 1);
     if (steps * nb > c->uniforms_cap) FAIL(VX_EINVAL, "too many uniforms (%ld steps)", steps);
     std::vector<float> u((size_t)steps * nb);
     for (long t = 0; t < steps; ++t)
