@@ -20,20 +20,33 @@
 namespace vx {
 
 constexpr int QB = 128, KT = 32, K_LD = 68, V_LD = 64;
+constexpr float MASKED = -1e30f;     // finite stand-in for -inf: exp_bf() maps it to exactly 0 without a NaN path
+
+// Branch-free exp for softmax arguments (x <= 0): exp(x) = 2^(x*log2e) with the product carried in two floats
+// (hi + lo) so the error stays at the ulp level of v_exp_f32 for |x| up to ~100 instead of growing with |x|.
+// libm's expf compiles to a conditional block per call, which splits the tile loop into 19 basic blocks and stops the
+// scheduler from overlapping the softmax with the MFMAs.
+__device__ __forceinline__ float exp_bf(float x) {
+  const float L2E = 1.44269504088896341f, L2E_LO = 1.925963033500649e-08f, LN2 = 0.6931471805599453f;
+  const float ph = x * L2E;
+  const float pl = fmaf(x, L2E, -ph) + x * L2E_LO;
+  const float e = __builtin_amdgcn_exp2f(ph);
+  return fmaf(e, pl * LN2, e);
+}
 
 __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                           const int* __restrict__ seq_off,
                                                           const int* __restrict__ seq_len,
                                                           const int* __restrict__ prefix_len) {
-  __shared__ __attribute__((aligned(16))) float Ks[KT * K_LD];
-  __shared__ __attribute__((aligned(16))) float Vs[KT * V_LD];
+  __shared__ __attribute__((aligned(16))) float Ks[2][KT * K_LD];
+  __shared__ __attribute__((aligned(16))) float Vs[2][KT * V_LD];
 
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB;
   const int len = seq_len[b];
   if (q0 >= len) return;
   const long row0 = seq_off[b];
   const int S = prefix_len ? prefix_len[b] : 0x7fffffff;       // keys < S are visible to everyone
-  const bool causal = prefix_len != nullptr;
+  const bool causal = prefix_len != nullptr;   // only narrows the block's key range below
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5, l31 = lane & 31;
   const int qi = q0 + wid * 32 + l31;                          // this lane's query (sequence-local index)
@@ -51,19 +64,15 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
     }
   }
 
-  // block-uniform key range; wave-uniform early-out bound
+  // block-uniform key range
   const int q_last = (q0 + QB - 1 < len ? q0 + QB - 1 : len - 1);
   int kv_end = len;
   if (causal) kv_end = (q_last < S) ? S : (q_last + 1 < len ? q_last + 1 : len);
-  int wq_last = q0 + wid * 32 + 31;
-  if (wq_last > len - 1) wq_last = len - 1;
-  int wave_kv_end = len;
-  if (causal) wave_kv_end = (wq_last < S) ? S : wq_last + 1;   // keys >= this are hidden from the whole wave
 
   f32x16 o[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = MASKED, l_run = 0.f;
 
   // staging map: float4 index f = tid + 256*i over 32 keys x 16 float4
   const float* kbase = qkv + row0 * (long)(3 * D_MODEL) + D_MODEL + h * D_HEAD;
@@ -79,45 +88,68 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
       rv[i] = *reinterpret_cast<const f32x4*>(vbase + kk * (long)(3 * D_MODEL) + c4);
     }
   };
-  issue(0);
-
-  for (int k0 = 0; k0 < kv_end; k0 += KT) {
-    __syncthreads();
+  auto stage_write = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int f = tid + 256 * i, key = f >> 4, c4 = (f & 15) * 4;
-      *reinterpret_cast<f32x4*>(&Ks[key * K_LD + c4]) = rk[i];
-      *reinterpret_cast<f32x4*>(&Vs[key * V_LD + c4]) = rv[i];
+      *reinterpret_cast<f32x4*>(&Ks[buf][key * K_LD + c4]) = rk[i];
+      *reinterpret_cast<f32x4*>(&Vs[buf][key * V_LD + c4]) = rv[i];
     }
-    __syncthreads();
-    if (k0 + KT < kv_end) issue(k0 + KT);
-    if (k0 >= wave_kv_end) continue;                           // wave-uniform: nothing visible in this tile
-
+  };
+  // S^T tile = K_tile . Q^T: 32 MFMAs, A fragment from LDS, B = Q registers
+  auto qk = [&](int buf) {
     f32x16 s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const f32x4 kf = *reinterpret_cast<const f32x4*>(&Ks[l31 * K_LD + c * 8 + hi * 4]);
+      const f32x4 kf = *reinterpret_cast<const f32x4*>(&Ks[buf][l31 * K_LD + c * 8 + hi * 4]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qreg[c * 4 + j], s, 0, 0, 0);
     }
-    // s[r] = score(q = qi, key = k0 + (r&3) + 8*(r>>2) + 4*hi)
-    float m_tile = -INFINITY;
+    return s;
+  };
+
+  // Software pipeline (two LDS buffers): iteration t issues the QK^T MFMAs of tile t+1 BEFORE the softmax of tile t,
+  // so the ~500 VALU instructions of the softmax sit in the shadow of 32 independent MFMAs of the same wave instead
+  // of idling the matrix pipe (all waves of a CU run in lock-step through identical tiles, so other waves do not fill
+  // that gap by themselves).  Tile t+2 travels global -> registers during iteration t and is written to LDS at its end.
+  const int ntiles = (kv_end + KT - 1) / KT;
+  issue(0);
+  stage_write(0);
+  __syncthreads();
+  if (1 < ntiles) issue(KT);
+  f32x16 s_cur = qk(0);
+  if (1 < ntiles) stage_write(1);
+  __syncthreads();
+  if (2 < ntiles) issue(2 * KT);
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int k0 = t * KT, cur = t & 1;
+    // ONE basic block per tile (no branches) so the scheduler can interleave: QK^T of tile t+1 (when there is no tile
+    // t+1 the product reads a stale buffer and is discarded), softmax of tile t, P.V of tile t.  Fully hidden tiles
+    // simply contribute exp(-1e30) = 0.
+    f32x16 s_next = qk(cur ^ 1);
+    // s_cur[r] = score(q = qi, key = k0 + (r&3) + 8*(r>>2) + 4*hi)
+    float m_tile = MASKED;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kj = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      bool vis = kj < len;
-      if (causal) vis = vis && (kj < S || (qi >= S && kj <= qi));
-      s[r] = vis ? s[r] : -INFINITY;
-      m_tile = fmaxf(m_tile, s[r]);
+      // branch-free visibility (S = INT_MAX when unmasked): in range, and (text key, or causal audio key)
+      const bool vis = (kj < len) & ((kj < S) | ((qi >= S) & (kj <= qi)));
+      s_cur[r] = vis ? s_cur[r] : MASKED;
+      m_tile = fmaxf(m_tile, s_cur[r]);
     }
-    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+    {  // other half of the keys lives in lane ^ 32: v_permlane32_swap is a VALU op (no LDS round trip like ds_bpermute)
+      const unsigned u = __builtin_bit_cast(unsigned, m_tile);
+      const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+      m_tile = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+    }
     const float m_new = fmaxf(m_run, m_tile);                  // finite: key 0 is visible to every query
-    const float alpha = expf(m_run - m_new);
+    const float alpha = exp_bf(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - m_new); psum += s[r]; }
+    for (int r = 0; r < 16; ++r) { s_cur[r] = exp_bf(s_cur[r] - m_new); psum += s_cur[r]; }
     l_run = l_run * alpha + psum;
     m_run = m_new;
 #pragma unroll
@@ -125,11 +157,23 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = (r & 3) + 8 * (r >> 2) + 4 * hi;
-      const float v0 = Vs[key * V_LD + l31];
-      const float v1 = Vs[key * V_LD + 32 + l31];
-      o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[r], o[0], 0, 0, 0);
-      o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[r], o[1], 0, 0, 0);
+      const float v0 = Vs[cur][key * V_LD + l31];
+      const float v1 = Vs[cur][key * V_LD + 32 + l31];
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s_cur[r], o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s_cur[r], o[1], 0, 0, 0);
     }
+    // Scheduling recipe for this block: pair each of the 32 QK^T MFMAs (independent of the softmax) with a slice of the
+    // softmax VALU stream; the compiler otherwise emits MFMA x32, VALU x230, MFMA x32 and the matrix pipe idles.
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);       // 7 VALU
+    }
+    s_cur = s_next;
+    __syncthreads();                                           // everyone is done reading buffer `cur`
+    if (t + 2 < ntiles) stage_write(cur);                      // registers hold tile t+2
+    __syncthreads();
+    if (t + 3 < ntiles) issue((t + 3) * KT);
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

@@ -26,8 +26,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
   __shared__ __attribute__((aligned(16))) float Ws[BN * LDS_LD];
 
-  // XCD-aware tile order: consecutive workgroups go to different XCDs (block b -> XCD b%8); remap so each
-  // XCD walks a contiguous run of tiles that share the same W column-panel (L2 reuse of W / A panels).
+  // Tile rasterisation for L2 reuse.  (1) XCD-aware: consecutive workgroup ids land on different XCDs (id % 8), each
+  // with a private 4 MiB L2, so ids are remapped to give every XCD one contiguous run of the tile order.
+  // (2) Inside that order tiles are grouped GM M-tiles deep: m runs fastest inside a group, then n, then the next
+  // group.  The ~96 workgroups an XCD keeps resident then cover a GM x 6 patch of the output: GM A-panels and 6
+  // W-panels are shared through L2 instead of 96 A-panels + 1 W-panel (4x fewer L2 fills per K step).
+  constexpr int GM = 16;
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / BN;
   const int nwg = tiles_m * tiles_n;
   int wg = blockIdx.x;
@@ -35,7 +39,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tm = wg % tiles_m, tn = wg / tiles_m;     // m fastest: neighbours share the W panel
+  const int per_group = GM * tiles_n;
+  const int grp = wg / per_group, in_grp = wg - grp * per_group;
+  const int gm0 = grp * GM;
+  const int gm_rows = (tiles_m - gm0 < GM) ? tiles_m - gm0 : GM;   // last group may be short
+  const int tm = gm0 + in_grp % gm_rows, tn = in_grp / gm_rows;
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -99,29 +107,48 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int jn = 0; jn < 2; ++jn)
-            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[jn][j], acc[i][jn], 0, 0, 0);
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[jn][j], a[i][j], acc[i][jn], 0, 0, 0);
     }
   }
 
-  // epilogue: acc[i][jn][r] = C[m0 + wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*hi][n0 + wn*64 + jn*32 + l31]
+  // The MFMA computes the TRANSPOSED tile (A operand = W rows, B operand = activation rows), so a lane owns one output
+  // row m and 4-element runs of consecutive n:
+  //   acc[i][jn][4*g4 + e] = C[m0 + wm*64 + i*32 + l31][n0 + wn*64 + jn*32 + 8*g4 + 4*hi + e]
+  // -> 16 float4 stores per lane instead of 64 dword stores (the epilogue is store-issue bound), bias / column scale /
+  // residual as float4 too.
 #pragma unroll
-  for (int jn = 0; jn < 2; ++jn) {
-    const int n = n0 + wn * 64 + jn * 32 + l31;
-    const float bias = g.bias ? g.bias[n] : 0.f;
-    const float cs = g.colscale ? g.colscale[n] : 1.f;
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm * 64 + i * 32 + l31;
+    if (m >= g.M) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int jn = 0; jn < 2; ++jn) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (m < g.M) {
-          float v = acc[i][jn][r] + bias;
-          if (g.act == ACT_RELU) v = fmaxf(v, 0.f);
-          else if (g.act == ACT_GELU) v = gelu_erf(v);
-          if (g.colscale) v = v * cs;
-          if (g.resid) v = g.resid[(long)m * g.ldr + n] + v;
-          g.C[(long)m * g.ldc + n] = v;
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int n = n0 + wn * 64 + jn * 32 + 8 * g4 + 4 * hi;
+        f32x4 v = {acc[i][jn][4 * g4], acc[i][jn][4 * g4 + 1], acc[i][jn][4 * g4 + 2], acc[i][jn][4 * g4 + 3]};
+        if (g.bias) {
+          const f32x4 bi = *reinterpret_cast<const f32x4*>(g.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bi[e];
         }
+        if (g.act == ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (g.act == ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (g.colscale) {
+          const f32x4 cs = *reinterpret_cast<const f32x4*>(g.colscale + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] * cs[e];
+        }
+        if (g.resid) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(g.resid + (long)m * g.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rr[e] + v[e];
+        }
+        *reinterpret_cast<f32x4*>(g.C + (long)m * g.ldc + n) = v;
       }
     }
   }
