@@ -198,3 +198,59 @@ def test_long_text_sliding_window_carries_prompt():
     ref = VocosOracle(vsd).decode_codes(np.concatenate([c1, c2], axis=1), 2)[0]
     assert wav.shape == ref.shape
     assert float(np.sqrt(np.mean((wav - ref) ** 2))) <= 1e-4
+
+
+def test_edge_cases_no_prompt_empty_result_and_two_microbatches():
+    """(a) no audio prompt at all (utils/generation.py:121-123: empty prompts, enroll_x_lens = 0);
+    (b) EOS as the very first sample -> the reference returns an EMPTY (1,0,8) tensor (prepend_bos path, see oracle);
+    (c) 35 rows = two AR micro-batches of the engine (32 + 3): every row still equals its batch-1 run."""
+    base = CASES["nl2_greedy_eos"]
+    m = get_model(base["num_layers"], base["seed"], base["eos_gain"], max_batch=40)
+    orc = _oracle(base)
+    # (a)
+    txt = synth.synth_text(11, 77)
+    empty = np.zeros((1, 0, 8), np.int64)
+    ref = orc.inference(txt[None], np.array([11]), empty, 0, top_k=1, prompt_language="en", text_language="en",
+                        force_eos_at=9)
+    out = m.inference(txt[None], np.array([11]), empty, 0, top_k=1, prompt_language="en", text_language="en",
+                      force_eos_at=9)
+    np.testing.assert_array_equal(out.numpy(), ref)
+    # (b)
+    a, t = synth.synth_prompt(12, 4, seed=5)
+    text = np.concatenate([t[0], txt])[None]
+    out0 = m.inference(text, np.array([text.shape[1]]), a, 4, top_k=1, prompt_language="en", text_language="en",
+                       force_eos_at=0)
+    assert tuple(out0.shape) == (1, 0, 8)
+    assert orc.inference(text, np.array([text.shape[1]]), a, 4, top_k=1, prompt_language="en", text_language="en",
+                         force_eos_at=0).shape == (1, 0, 8)
+    assert m.engine.vocos_decode([out0.numpy()[0]], 2)[0].shape == (0,) if m._vocos_sd is not None else True
+    # (c)
+    rows = []
+    for i in range(35):
+        ap, tp = synth.synth_prompt(5 + (i * 3) % 17, 2 + i % 5, seed=300 + i)
+        tx = np.concatenate([tp[0], synth.synth_text(4 + i % 6, 300 + i)])
+        rows.append(dict(text=tx, prompt=ap[0], enroll=tp.shape[1], prompt_language=("en", "zh", "ja")[i % 3],
+                         text_language=("en", "zh", "ja")[(i + 1) % 3]))
+    outs = m.inference_batch(rows, top_k=1, force_eos_at=6)
+    for i in (0, 13, 31, 32, 34):
+        r = rows[i]
+        ref = orc.inference(r["text"][None], np.array([len(r["text"])]), r["prompt"][None], r["enroll"], top_k=1,
+                            prompt_language=r["prompt_language"], text_language=r["text_language"], force_eos_at=6)[0]
+        np.testing.assert_array_equal(outs[i], ref)
+
+
+def test_engine_rejects_bad_arguments():
+    import vallex_amd
+    base = CASES["nl2_greedy_eos"]
+    m = get_model(base["num_layers"], base["seed"], base["eos_gain"])
+    a, t = synth.synth_prompt(8, 3, seed=1)
+    long_text = np.full(300, 7, np.int32)                     # > max_text (256)
+    with pytest.raises(vallex_amd.VallexHipError):
+        m.inference_batch([dict(text=long_text, prompt=a[0], enroll=3, prompt_language="en", text_language="en")], top_k=1)
+    bad = a[0].copy()
+    bad[0, 0] = 5000                                          # codebook id out of range
+    with pytest.raises(vallex_amd.VallexHipError):
+        m.inference_batch([dict(text=t[0], prompt=bad, enroll=3, prompt_language="en", text_language="en")], top_k=1)
+    with pytest.raises(vallex_amd.VallexHipError):
+        m.inference_batch([dict(text=t[0], prompt=a[0], enroll=3, prompt_language="en", text_language="en")], top_k=1,
+                          temperature=0.0)

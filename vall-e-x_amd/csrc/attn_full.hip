@@ -125,35 +125,56 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
   if (2 < ntiles) issue(2 * KT);
 
   for (int t = 0; t < ntiles; ++t) {
-    const int k0 = t * KT, cur = t & 1;
-    // ONE basic block per tile (no branches) so the scheduler can interleave: QK^T of tile t+1 (when there is no tile
-    // t+1 the product reads a stale buffer and is discarded), softmax of tile t, P.V of tile t.  Fully hidden tiles
-    // simply contribute exp(-1e30) = 0.
-    f32x16 s_next = qk(cur ^ 1);
-    // s_cur[r] = score(q = qi, key = k0 + (r&3) + 8*(r>>2) + 4*hi)
-    float m_tile = MASKED;
+    const int k0 = t * KT, cur = t & 1, nxt = cur ^ 1;
+    // ---- phase 1: QK^T of tile t+1 (32 MFMAs) with the softmax of tile t threaded through it.
+    // In-order issue + dependent MFMA chains mean VALU work only overlaps the matrix pipe if it physically sits between
+    // the MFMAs, so the tile is cut into 16 steps of [2 MFMAs | one slice of the softmax], fenced by sched_barrier(0).
+    // (When there is no tile t+1 the product reads a stale buffer and is discarded; fully hidden tiles contribute
+    // exp(-1e30) = 0.)   s_cur[r] = score(q = qi, key = k0 + (r&3) + 8*(r>>2) + 4*hi)
+    f32x16 sA;                                                 // one chain: dependent latency == issue interval (64 cyc)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kj = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      // branch-free visibility (S = INT_MAX when unmasked): in range, and (text key, or causal audio key)
-      const bool vis = (kj < len) & ((kj < S) | ((qi >= S) & (kj <= qi)));
-      s_cur[r] = vis ? s_cur[r] : MASKED;
-      m_tile = fmaxf(m_tile, s_cur[r]);
+    for (int r = 0; r < 16; ++r) sA[r] = 0.f;
+    f32x4 kfA, kfB;
+    float m_new = m_run, alpha = 1.f, psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int cp = i >> 2, j = i & 3;
+      if (j == 0) {
+        kfA = *reinterpret_cast<const f32x4*>(&Ks[nxt][l31 * K_LD + (2 * cp) * 8 + hi * 4]);
+        kfB = *reinterpret_cast<const f32x4*>(&Ks[nxt][l31 * K_LD + (2 * cp + 1) * 8 + hi * 4]);
+      }
+      sA = __builtin_amdgcn_mfma_f32_32x32x2f32(kfA[j], qreg[(2 * cp) * 4 + j], sA, 0, 0, 0);
+      sA = __builtin_amdgcn_mfma_f32_32x32x2f32(kfB[j], qreg[(2 * cp + 1) * 4 + j], sA, 0, 0, 0);
+      if (i < 4) {                                             // steps 0-3: visibility mask, 4 keys per step
+#pragma unroll
+        for (int r = 4 * i; r < 4 * i + 4; ++r) {
+          const int kj = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          // branch-free (S = INT_MAX when unmasked): in range, and (text key, or causal audio key)
+          const bool vis = (kj < len) & ((kj < S) | ((qi >= S) & (kj <= qi)));
+          s_cur[r] = vis ? s_cur[r] : MASKED;
+        }
+      } else if (i == 4) {                                     // step 4: running max (other 16 keys live in lane ^ 32)
+        float m_tile = MASKED;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m_tile = fmaxf(m_tile, s_cur[r]);
+        const unsigned u = __builtin_bit_cast(unsigned, m_tile);
+        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // VALU op, no LDS round trip
+        m_tile = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+        m_new = fmaxf(m_run, m_tile);                          // finite: key 0 is visible to every query
+        alpha = exp_bf(m_run - m_new);
+      } else if (i < 13) {                                     // steps 5-12: two exps per step
+#pragma unroll
+        for (int r = 2 * (i - 5); r < 2 * (i - 5) + 2; ++r) { s_cur[r] = exp_bf(s_cur[r] - m_new); psum += s_cur[r]; }
+      } else if (i == 13) {
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+      } else {                                                 // steps 14-15: rescale the two halves of O
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i - 14][r] *= alpha;
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    {  // other half of the keys lives in lane ^ 32: v_permlane32_swap is a VALU op (no LDS round trip like ds_bpermute)
-      const unsigned u = __builtin_bit_cast(unsigned, m_tile);
-      const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-      m_tile = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
-    }
-    const float m_new = fmaxf(m_run, m_tile);                  // finite: key 0 is visible to every query
-    const float alpha = exp_bf(m_run - m_new);
-    float psum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s_cur[r] = exp_bf(s_cur[r] - m_new); psum += s_cur[r]; }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+    // ---- phase 2: O^T += V^T . P^T, 32 MFMAs fed by ds_read of V
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -162,14 +183,8 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
       o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s_cur[r], o[0], 0, 0, 0);
       o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s_cur[r], o[1], 0, 0, 0);
     }
-    // Scheduling recipe for this block: pair each of the 32 QK^T MFMAs (independent of the softmax) with a slice of the
-    // softmax VALU stream; the compiler otherwise emits MFMA x32, VALU x230, MFMA x32 and the matrix pipe idles.
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // 1 MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);       // 7 VALU
-    }
-    s_cur = s_next;
+    for (int r = 0; r < 16; ++r) s_cur[r] = sA[r];
     __syncthreads();                                           // everyone is done reading buffer `cur`
     if (t + 2 < ntiles) stage_write(cur);                      // registers hold tile t+2
     __syncthreads();
