@@ -40,6 +40,7 @@ typedef struct vx_config {
   int32_t use_graph;       /* 1: replay the AR step as a hipGraph */
   int32_t with_vocos;      /* 1: allocate the Vocos head */
   int32_t debug_taps;      /* 1: keep per-layer activations for vx_read_tap */
+  int32_t with_encodec;    /* 1: allocate the EnCodec SEANet decoder arena (needs the "encodec.*" tensors) */
 } vx_config;
 
 /* ---- lifetime -------------------------------------------------------------------------------------------
@@ -101,6 +102,14 @@ int vx_infer(vx_ctx* ctx, const vx_batch* b, const vx_sampling* s, int64_t* out_
  * codes [batch][codes_stride][8] int64, lens [batch] frames; audio [batch][audio_stride] fp32, 320*len samples each. */
 int vx_vocos_decode(vx_ctx* ctx, const int64_t* codes, int32_t codes_stride, const int32_t* lens, int32_t batch,
                     int32_t bandwidth_id, float* audio, int64_t audio_stride);
+
+/* replaces: AudioTokenizer.decode(frames) -> codec.decode (EnCodec 24 kHz SEANet decoder: RVQ sum, Conv1d, 2-layer LSTM,
+ * 4 x [ELU, ConvTranspose1d, ResnetBlock], ELU, Conv1d), data/tokenizer.py:95-96 -- the legacy vocoder the reference keeps
+ * beside Vocos (README.md:29-30).  Tensors are loaded as "encodec." + {quantizer.{q}.embed, decoder.{i}.weight|bias,
+ * decoder.{i}.block1|block3|shortcut.weight|bias, decoder.1.lstm.*} with weight-norm already folded.
+ * codes [batch][codes_stride][8] int64, lens [batch]; audio [batch][audio_stride] fp32, 320*len samples each. */
+int vx_encodec_decode(vx_ctx* ctx, const int64_t* codes, int32_t codes_stride, const int32_t* lens, int32_t batch,
+                      float* audio, int64_t audio_stride);
 
 /* ---- step-level entries (kernel-level parity tests; same kernels as vx_infer) ---------------------------- */
 /* first ar_decoder.infer call (models/vallex.py:528-562): embeds, runs the prefix-LM prefill, fills the KV arena,

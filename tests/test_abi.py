@@ -30,7 +30,7 @@ def test_header_symbols_exported(lib):
 def test_struct_layout_matches_header():
     import ctypes as C
     from vallex_amd._capi import vx_batch, vx_config, vx_sampling
-    assert C.sizeof(vx_config) == 8 * 4
+    assert C.sizeof(vx_config) == 9 * 4
     assert vx_batch.text_lens.offset == 32 and C.sizeof(vx_batch) == 64
     assert vx_sampling.seed.offset == 24 and vx_sampling.best_of.offset == 40 and C.sizeof(vx_sampling) == 56
 

@@ -1,0 +1,71 @@
+"""EnCodec SEANet decoder.  CPU: oracle vs the committed output of the installed transformers port,
+and the state-dict normalisation; GPU: the HIP decoder vs the same goldens."""
+import os
+
+import numpy as np
+import pytest
+
+import vallex_amd  # noqa: F401
+from oracle.encodec_oracle import EncodecDecoderOracle, encodec_state_dict
+from oracle.make_golden_encodec import CASES, GOLD, case_codes
+from vallex_amd.data.tokenizer import AudioTokenizer, canonical_encodec_state_dict
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_matches_transformers_port(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))["audio"]
+    out = EncodecDecoderOracle(encodec_state_dict(3)).decode(case_codes(name))
+    assert out.shape == g.shape
+    np.testing.assert_allclose(out, g, atol=1e-6, rtol=0)
+
+
+def test_state_dict_normalisation_folds_weight_norm():
+    sd = encodec_state_dict(3)
+    rng = np.random.default_rng(0)
+    pkg = {}                                        # the `encodec` package's naming, weight_g / weight_v form
+    for k, v in sd.items():
+        if k.startswith("quantizer."):
+            pkg[f"quantizer.vq.layers.{k.split('.')[1]}._codebook.embed"] = v
+        elif ".lstm." in k:
+            pkg["decoder.model." + k[len("decoder."):]] = v
+        else:
+            i, rest = k[len("decoder."):].split(".", 1)
+            sub, leaf = ("", rest) if rest in ("weight", "bias") else rest.rsplit(".", 1)
+            sub = {"": "", "block1": "block.1.", "block3": "block.3.", "shortcut": "shortcut."}[sub]
+            inner = "convtr.convtr." if (int(i) in (3, 6, 9, 12) and sub == "") else "conv.conv."
+            if leaf == "bias":
+                pkg[f"decoder.model.{i}.{sub}{inner}bias"] = v
+            else:
+                g = rng.uniform(0.5, 2.0, size=(v.shape[0],) + (1,) * (v.ndim - 1)).astype(np.float32)
+                n = np.sqrt((v.astype(np.float64) ** 2).reshape(v.shape[0], -1).sum(1)).reshape(g.shape)
+                pkg[f"decoder.model.{i}.{sub}{inner}weight_g"] = (n * 1.0).astype(np.float32)      # g = ||v||  ->  w = v
+                pkg[f"decoder.model.{i}.{sub}{inner}weight_v"] = v
+    pkg["encoder.model.0.conv.conv.weight_v"] = np.zeros((4, 4, 4), np.float32)                 # ignored
+    same = canonical_encodec_state_dict(sd)                          # canonical names pass through unchanged
+    assert set(same) == set(sd) and all(np.array_equal(same[k], sd[k]) for k in sd)
+    canon = canonical_encodec_state_dict(pkg)
+    assert set(canon) == set(sd)
+    for k in sd:
+        np.testing.assert_allclose(canon[k], sd[k], atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_decoder_matches_transformers_port():
+    from tests._util import get_model
+    m = get_model(2, 0, 2.5, max_new=64, max_batch=4)
+    m.load_encodec_state_dict(encodec_state_dict(3))
+    tok = AudioTokenizer(device="cuda:0", valle=m)
+    for name in CASES:
+        codes = case_codes(name)                                        # (B, T, 8)
+        g = np.load(os.path.join(GOLD, name + ".npz"))["audio"]
+        import torch
+        out = tok.decode([(torch.from_numpy(codes).permute(0, 2, 1), None)]).numpy()[:, 0]
+        assert out.shape == g.shape
+        err = np.abs(out - g)
+        assert err.max() <= 2e-5, (name, err.max())                      # audio amplitude ~0.15: fp32 reassociation only
+        assert float(np.sqrt(np.mean(err ** 2))) <= 1e-5
+    # ragged batch: two sequences of different length decoded together == decoded alone
+    c0, c1 = case_codes("encodec_T37")[0], case_codes("encodec_T5")[0]
+    both = m.engine.encodec_decode([c0, c1])
+    np.testing.assert_allclose(both[1], np.load(os.path.join(GOLD, "encodec_T5.npz"))["audio"][0], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(both[0], np.load(os.path.join(GOLD, "encodec_T37.npz"))["audio"][0], atol=2e-5, rtol=0)

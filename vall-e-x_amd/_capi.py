@@ -26,7 +26,7 @@ class VallexHipError(RuntimeError):
 class vx_config(C.Structure):
     _fields_ = [("num_layers", C.c_int32), ("max_batch", C.c_int32), ("max_text", C.c_int32),
                 ("max_prompt", C.c_int32), ("max_new", C.c_int32), ("use_graph", C.c_int32),
-                ("with_vocos", C.c_int32), ("debug_taps", C.c_int32)]
+                ("with_vocos", C.c_int32), ("debug_taps", C.c_int32), ("with_encodec", C.c_int32)]
 
 
 class vx_batch(C.Structure):
@@ -45,7 +45,7 @@ class vx_sampling(C.Structure):
 
 # every symbol include/vallex_hip.h declares (tests/test_abi.py checks the library exports exactly these)
 SYMBOLS = ["vx_create", "vx_destroy", "vx_last_error", "vx_synchronize", "vx_load_tensor", "vx_finalize_weights",
-           "vx_infer", "vx_vocos_decode", "vx_ar_prefill", "vx_ar_logits", "vx_ar_step", "vx_nar", "vx_read_tap",
+           "vx_infer", "vx_vocos_decode", "vx_encodec_decode", "vx_ar_prefill", "vx_ar_logits", "vx_ar_step", "vx_nar", "vx_read_tap",
            "vx_prof_enable", "vx_prof_get", "vx_prof_reset", "vx_bench_kernel", "vx_last_stats"]
 
 _lib = None
@@ -73,6 +73,7 @@ def load_library() -> C.CDLL:
     lib.vx_infer.argtypes = [ctx, P(vx_batch), P(vx_sampling), P(C.c_int64), C.c_int32, P(C.c_int32)]
     lib.vx_vocos_decode.argtypes = [ctx, P(C.c_int64), C.c_int32, P(C.c_int32), C.c_int32, C.c_int32, P(C.c_float),
                                     C.c_int64]
+    lib.vx_encodec_decode.argtypes = [ctx, P(C.c_int64), C.c_int32, P(C.c_int32), C.c_int32, P(C.c_float), C.c_int64]
     lib.vx_ar_prefill.argtypes = [ctx, P(vx_batch)]
     lib.vx_ar_logits.argtypes = [ctx, P(C.c_float)]
     lib.vx_ar_step.argtypes = [ctx, P(C.c_int32)]
@@ -124,10 +125,10 @@ class Engine:
 
     def __init__(self, device_id: int = 0, num_layers: int = 12, max_batch: int = 32, max_text: int = 512,
                  max_prompt: int = 1024, max_new: int = 2048, use_graph: bool = True, with_vocos: bool = True,
-                 debug_taps: bool = False):
+                 debug_taps: bool = False, with_encodec: bool = False):
         self.lib = load_library()
         self.cfg = vx_config(num_layers, max_batch, max_text, max_prompt, max_new, int(use_graph), int(with_vocos),
-                             int(debug_taps))
+                             int(debug_taps), int(with_encodec))
         self.ctx = C.c_void_p()
         rc = self.lib.vx_create(device_id, C.byref(self.cfg), C.byref(self.ctx))
         if rc != VX_OK:
@@ -203,6 +204,18 @@ class Engine:
         audio = np.zeros((n, stride * 320), np.float32)
         self._chk(self.lib.vx_vocos_decode(self.ctx, _ptr(buf, C.c_int64), stride, _ptr(lens, C.c_int32), n,
                                            int(bandwidth_id), _ptr(audio, C.c_float), stride * 320))
+        return [audio[i, : lens[i] * 320].copy() for i in range(n)]
+
+    def encodec_decode(self, codes: Sequence[np.ndarray]):
+        n = len(codes)
+        lens = np.array([c.shape[0] for c in codes], np.int32)
+        stride = max(1, int(lens.max()))
+        buf = np.zeros((n, stride, 8), np.int64)
+        for i, c in enumerate(codes):
+            buf[i, : c.shape[0]] = c
+        audio = np.zeros((n, stride * 320), np.float32)
+        self._chk(self.lib.vx_encodec_decode(self.ctx, _ptr(buf, C.c_int64), stride, _ptr(lens, C.c_int32), n,
+                                             _ptr(audio, C.c_float), stride * 320))
         return [audio[i, : lens[i] * 320].copy() for i in range(n)]
 
     # ---- step-level (tests) ----

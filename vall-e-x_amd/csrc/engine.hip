@@ -99,6 +99,15 @@ struct vx_ctx {
   int64_t st_steps = 0, st_frames = 0;
   double st_ar_ms = 0, st_nar_ms = 0;
 
+  // EnCodec decoder (optional)
+  bool has_encodec = false;
+  float *ec_codebook = nullptr, *ec_w0 = nullptr, *ec_lstm_b[2] = {nullptr, nullptr}, *ec_whh_p[2] = {nullptr, nullptr};
+  float *ec_wT[4] = {}, *ec_bT[4] = {}, *ec_w1[4] = {}, *ec_w3[4] = {};
+  float *ec_e0 = nullptr, *ec_x0 = nullptr, *ec_y1 = nullptr, *ec_y2 = nullptr, *ec_xg = nullptr, *ec_col = nullptr,
+        *ec_a = nullptr, *ec_sc = nullptr, *ec_out = nullptr, *ec_h = nullptr, *ec_audio = nullptr, *ec_hp = nullptr,
+        *ec_c = nullptr, *ec_pg = nullptr;
+  long ec_frames_cap = 0;
+
   // vocos arena
   float *vfeat = nullptr, *vcol = nullptr, *vx0 = nullptr, *vx1 = nullptr, *vhid = nullptr, *vo = nullptr,
         *vreim = nullptr, *vframes = nullptr, *vaudio = nullptr;
@@ -866,6 +875,125 @@ int vx_finalize_weights(vx_ctx* c) {
     if ((e = dev_alloc(c, &c->vaudio, (size_t)c->cfg.max_batch * c->cfg.max_new * 320))) return e;
     c->has_vocos = true;
   }
+  // ---- EnCodec SEANet decoder (optional; data/tokenizer.py:95-96 path) ----
+  if (c->cfg.with_encodec && c->w.count("encodec.decoder.0.weight")) {
+    const int ratios[4] = {8, 5, 4, 2};
+#define NEED(...) if ((e = need(c, __VA_ARGS__))) return e
+    for (int q = 0; q < N_Q; ++q) NEED("encodec.quantizer." + std::to_string(q) + ".embed", {1024, 128});
+    NEED("encodec.decoder.0.weight", {512, 128, 7});
+    NEED("encodec.decoder.0.bias", {512});
+    for (int l = 0; l < 2; ++l) {
+      const std::string sfx = "_l" + std::to_string(l);
+      NEED("encodec.decoder.1.lstm.weight_ih" + sfx, {2048, 512});
+      NEED("encodec.decoder.1.lstm.weight_hh" + sfx, {2048, 512});
+      NEED("encodec.decoder.1.lstm.bias_ih" + sfx, {2048});
+      NEED("encodec.decoder.1.lstm.bias_hh" + sfx, {2048});
+    }
+    {
+      int C = 512;
+      for (int st = 0; st < 4; ++st) {
+        const int r = ratios[st], O = C / 2;
+        const std::string pT = "encodec.decoder." + std::to_string(3 + 3 * st), pR = "encodec.decoder." + std::to_string(4 + 3 * st);
+        NEED(pT + ".weight", {C, O, 2 * r});
+        NEED(pT + ".bias", {O});
+        NEED(pR + ".block1.weight", {O / 2, O, 3});
+        NEED(pR + ".block1.bias", {O / 2});
+        NEED(pR + ".block3.weight", {O, O / 2, 1});
+        NEED(pR + ".block3.bias", {O});
+        NEED(pR + ".shortcut.weight", {O, O, 1});
+        NEED(pR + ".shortcut.bias", {O});
+        C = O;
+      }
+    }
+    NEED("encodec.decoder.15.weight", {1, 32, 7});
+    NEED("encodec.decoder.15.bias", {1});
+#undef NEED
+    auto fetch = [&](const std::string& name, std::vector<float>& host) -> int {
+      const Tensor& t = c->w[name];
+      host.resize(t.n);
+      HIPCHK(hipMemcpy(host.data(), t.d, t.n * sizeof(float), hipMemcpyDeviceToHost));
+      return VX_OK;
+    };
+    auto upload = [&](const std::vector<float>& host, float** dev) -> int {
+      if (int e2 = dev_alloc(c, dev, host.size(), false)) return e2;
+      HIPCHK(hipMemcpy(*dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+      return VX_OK;
+    };
+    std::vector<float> w, w2, b, b2;
+    // RVQ codebooks, concatenated [8*1024][128]
+    if ((e = dev_alloc(c, &c->ec_codebook, (size_t)N_Q * 1024 * 128, false))) return e;
+    for (int q = 0; q < N_Q; ++q)
+      HIPCHK(hipMemcpy(c->ec_codebook + (size_t)q * 1024 * 128, W(c, "encodec.quantizer." + std::to_string(q) + ".embed"),
+                       (size_t)1024 * 128 * sizeof(float), hipMemcpyDeviceToDevice));
+    // first conv (512,128,7) -> [512][tap*128 + c]
+    if ((e = fetch("encodec.decoder.0.weight", w))) return e;
+    w2.assign((size_t)512 * 896, 0.f);
+    for (int o = 0; o < 512; ++o)
+      for (int ch = 0; ch < 128; ++ch)
+        for (int tap = 0; tap < 7; ++tap) w2[(size_t)o * 896 + tap * 128 + ch] = w[((size_t)o * 128 + ch) * 7 + tap];
+    if ((e = upload(w2, &c->ec_w0))) return e;
+    for (int l = 0; l < 2; ++l) {
+      const std::string sfx = "_l" + std::to_string(l);
+      if ((e = fetch("encodec.decoder.1.lstm.bias_ih" + sfx, b))) return e;
+      if ((e = fetch("encodec.decoder.1.lstm.bias_hh" + sfx, b2))) return e;
+      for (size_t i = 0; i < b.size(); ++i) b[i] += b2[i];
+      if ((e = upload(b, &c->ec_lstm_b[l]))) return e;
+      if ((e = pack(c, W(c, "encodec.decoder.1.lstm.weight_hh" + sfx), 2048, 512, 2048, &c->ec_whh_p[l]))) return e;
+    }
+    {
+      int C = 512;
+      for (int st = 0; st < 4; ++st) {
+        const int r = ratios[st], O = C / 2, K = 2 * r;
+        const std::string pT = "encodec.decoder." + std::to_string(3 + 3 * st), pR = "encodec.decoder." + std::to_string(4 + 3 * st);
+        // ConvTranspose1d weight (C, O, 2r) -> [(ph*O + o)][tap*C + c] = w[c][o][ph + tap*r]
+        if ((e = fetch(pT + ".weight", w))) return e;
+        w2.assign((size_t)r * O * 2 * C, 0.f);
+        for (int ph = 0; ph < r; ++ph)
+          for (int o = 0; o < O; ++o)
+            for (int tap = 0; tap < 2; ++tap)
+              for (int ch = 0; ch < C; ++ch)
+                w2[((size_t)ph * O + o) * (2 * C) + tap * C + ch] = w[((size_t)ch * O + o) * K + ph + tap * r];
+        if ((e = upload(w2, &c->ec_wT[st]))) return e;
+        if ((e = fetch(pT + ".bias", b))) return e;
+        b2.resize((size_t)r * O);
+        for (int ph = 0; ph < r; ++ph)
+          for (int o = 0; o < O; ++o) b2[(size_t)ph * O + o] = b[o];
+        if ((e = upload(b2, &c->ec_bT[st]))) return e;
+        // resblock conv k3 (O/2, O, 3) -> [O/2][tap*O + c]
+        if ((e = fetch(pR + ".block1.weight", w))) return e;
+        w2.assign((size_t)(O / 2) * 3 * O, 0.f);
+        for (int o = 0; o < O / 2; ++o)
+          for (int ch = 0; ch < O; ++ch)
+            for (int tap = 0; tap < 3; ++tap) w2[(size_t)o * 3 * O + tap * O + ch] = w[((size_t)o * O + ch) * 3 + tap];
+        if ((e = upload(w2, &c->ec_w1[st]))) return e;
+        // resblock conv k1 (O, O/2, 1) -> [O][ldh], ldh = max(O/2, 32) (K of the GEMM must be a multiple of 32)
+        const int ldh = std::max(O / 2, 32);
+        if ((e = fetch(pR + ".block3.weight", w))) return e;
+        w2.assign((size_t)O * ldh, 0.f);
+        for (int o = 0; o < O; ++o)
+          for (int ch = 0; ch < O / 2; ++ch) w2[(size_t)o * ldh + ch] = w[(size_t)o * (O / 2) + ch];
+        if ((e = upload(w2, &c->ec_w3[st]))) return e;
+        C = O;
+      }
+    }
+    c->ec_frames_cap = (long)c->mbr * c->cfg.max_new;
+    const size_t Fc = (size_t)c->ec_frames_cap + 8;
+    if ((e = dev_alloc(c, &c->ec_e0, Fc * 128))) return e;
+    if ((e = dev_alloc(c, &c->ec_x0, Fc * 512))) return e;
+    if ((e = dev_alloc(c, &c->ec_y1, Fc * 512))) return e;
+    if ((e = dev_alloc(c, &c->ec_y2, Fc * 512))) return e;
+    if ((e = dev_alloc(c, &c->ec_xg, Fc * 2048))) return e;
+    if ((e = dev_alloc(c, &c->ec_col, Fc * 30720))) return e;
+    if ((e = dev_alloc(c, &c->ec_a, Fc * 10240))) return e;
+    if ((e = dev_alloc(c, &c->ec_sc, Fc * 10240))) return e;
+    if ((e = dev_alloc(c, &c->ec_out, Fc * 10240))) return e;
+    if ((e = dev_alloc(c, &c->ec_h, Fc * 10240))) return e;
+    if ((e = dev_alloc(c, &c->ec_audio, (size_t)c->mbr * c->cfg.max_new * 320))) return e;
+    if ((e = dev_alloc(c, &c->ec_hp, (size_t)MB * 512))) return e;
+    if ((e = dev_alloc(c, &c->ec_c, (size_t)MB * 512))) return e;
+    if ((e = dev_alloc(c, &c->ec_pg, (size_t)2 * MB * 2048))) return e;
+    c->has_encodec = true;
+  }
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipGetLastError());
   c->finalized = true;
@@ -1069,6 +1197,96 @@ int vx_vocos_decode(vx_ctx* c, const int64_t* codes, int32_t codes_stride, const
                           hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
+  return VX_OK;
+}
+
+// replaces: AudioTokenizer.decode -> codec.decode([(codes, None)]) (data/tokenizer.py:95-96): EnCodec 24 kHz SEANet decoder
+int vx_encodec_decode(vx_ctx* c, const int64_t* codes, int32_t codes_stride, const int32_t* lens, int32_t batch,
+                      float* audio, int64_t audio_stride) {
+  if (!c || !codes || !lens || !audio) return VX_EINVAL;
+  if (!c->finalized || !c->has_encodec) FAIL(VX_ESTATE, "EnCodec decoder weights not loaded");
+  if (batch <= 0) FAIL(VX_EINVAL, "bad batch");
+  HIPCHK(hipSetDevice(c->dev));
+  hipStream_t st = c->stream;
+  const int ratios[4] = {8, 5, 4, 2};
+  for (int r0 = 0; r0 < batch; r0 += c->mbr) {
+    const int nb = std::min(c->mbr, batch - r0);
+    std::vector<int> seq_off(nb), seq_len(nb), cd;
+    long F = 0;
+    int maxT = 0;
+    for (int i = 0; i < nb; ++i) {
+      const int T = lens[r0 + i];
+      if (T < 0 || T > c->cfg.max_new || T > codes_stride) FAIL(VX_EINVAL, "row %d: bad length", r0 + i);
+      if ((long)T * 320 > audio_stride) FAIL(VX_EINVAL, "audio_stride too small");
+      seq_off[i] = (int)F; seq_len[i] = T; maxT = std::max(maxT, T);
+      for (int t = 0; t < T; ++t)
+        for (int q = 0; q < N_Q; ++q) {
+          const int64_t v = codes[((long)(r0 + i) * codes_stride + t) * N_Q + q];
+          if (v < 0 || v >= AUDIO_VOCAB) FAIL(VX_EINVAL, "code out of range");
+          cd.push_back((int)v);
+        }
+      F += T;
+    }
+    if (F == 0) continue;
+    if (F > c->ec_frames_cap) FAIL(VX_EINVAL, "too many frames");
+    MetaBuilder mb(c);
+    const long o_off = mb.add(seq_off), o_len = mb.add(seq_len), o_cd = mb.add(cd);
+    if (int e = upload_meta(c)) return e;
+    const int* d_off = mb.dev(o_off);
+    const int* d_len = mb.dev(o_len);
+    // RVQ decode + first conv
+    launch_codebook_sum(mb.dev(o_cd), c->ec_codebook, c->ec_e0, (int)F, st);
+    launch_im2col_seq(c->ec_e0, 128, 7, 0, 0, d_off, d_len, 1, c->ec_col, 896, nb, maxT, st);
+    gemm(c, c->ec_col, 896, c->ec_w0, 896, W(c, "encodec.decoder.0.bias"), nullptr, 0, nullptr, c->ec_x0, 512, F, 512, 896,
+         ACT_NONE);
+    // 2-layer LSTM + skip: input projections as one GEMM per layer, the recurrence on the skinny MFMA GEMM
+    const float* lin = c->ec_x0;
+    for (int l = 0; l < 2; ++l) {
+      const std::string sfx = "_l" + std::to_string(l);
+      gemm(c, lin, 512, W(c, "encodec.decoder.1.lstm.weight_ih" + sfx), 512, c->ec_lstm_b[l], nullptr, 0, nullptr, c->ec_xg,
+           2048, F, 2048, 512, ACT_NONE);
+      HIPCHK(hipMemsetAsync(c->ec_hp, 0, (size_t)MB * 512 * sizeof(float), st));
+      HIPCHK(hipMemsetAsync(c->ec_c, 0, (size_t)MB * 512 * sizeof(float), st));
+      float* yout = l == 0 ? c->ec_y1 : c->ec_y2;
+      for (int t = 0; t < maxT; ++t) {
+        launch_skinny_gemm(c->ec_whh_p[l], c->ec_hp, c->ec_pg, 2048, 512, 2, nullptr, st);
+        launch_lstm_cell(c->ec_pg, 2, c->ec_xg, d_off, d_len, t, c->ec_c, c->ec_hp, yout, l == 1 ? c->ec_x0 : nullptr, nb, st);
+      }
+      lin = yout;
+    }
+    // 4 x [ELU, ConvTranspose1d, ResnetBlock]
+    const float* cur = c->ec_y2;
+    int C = 512;
+    long R = 1;
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int r = ratios[s4], O = C / 2;
+      launch_im2col_seq(cur, C, 2, 1, 1, d_off, d_len, (int)R, c->ec_col, 2 * C, nb, (long)maxT * R, st);
+      gemm(c, c->ec_col, 2 * C, c->ec_wT[s4], 2 * C, c->ec_bT[s4], nullptr, 0, nullptr, c->ec_a, r * O, F * R, r * O, 2 * C,
+           ACT_NONE);
+      R *= r;
+      C = O;
+      const std::string pR = "encodec.decoder." + std::to_string(4 + 3 * s4);
+      const long M = F * R;
+      const int ldh = std::max(C / 2, 32);
+      gemm(c, c->ec_a, C, W(c, pR + ".shortcut.weight"), C, W(c, pR + ".shortcut.bias"), nullptr, 0, nullptr, c->ec_sc, C, M, C,
+           C, ACT_NONE);
+      launch_im2col_seq(c->ec_a, C, 3, 0, 1, d_off, d_len, (int)R, c->ec_col, 3 * C, nb, (long)maxT * R, st);
+      if (ldh != C / 2) HIPCHK(hipMemsetAsync(c->ec_h, 0, (size_t)M * ldh * sizeof(float), st));
+      gemm(c, c->ec_col, 3 * C, c->ec_w1[s4], 3 * C, W(c, pR + ".block1.bias"), nullptr, 0, nullptr, c->ec_h, ldh, M, C / 2,
+           3 * C, ACT_ELU);
+      gemm(c, c->ec_h, ldh, c->ec_w3[s4], ldh, W(c, pR + ".block3.bias"), c->ec_sc, C, nullptr, c->ec_out, C, M, C, ldh,
+           ACT_NONE);
+      cur = c->ec_out;
+    }
+    const long astride = (long)c->cfg.max_new * 320;
+    launch_final_conv(cur, W(c, "encodec.decoder.15.weight"), W(c, "encodec.decoder.15.bias"), d_off, d_len, (int)R,
+                      c->ec_audio, astride, nb, (long)maxT * R, st);
+    for (int i = 0; i < nb; ++i)
+      HIPCHK(hipMemcpyAsync(audio + (long)(r0 + i) * audio_stride, c->ec_audio + (long)i * astride,
+                            (size_t)seq_len[i] * 320 * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+  }
   return VX_OK;
 }
 

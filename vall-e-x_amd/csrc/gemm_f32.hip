@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   // group.  The ~96 workgroups an XCD keeps resident then cover a GM x 6 patch of the output: GM A-panels and 6
   // W-panels are shared through L2 instead of 96 A-panels + 1 W-panel (4x fewer L2 fills per K step).
   constexpr int GM = 16;
-  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / BN;
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
   int wg = blockIdx.x;
   {
@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     m = m < g.M ? m : g.M - 1;
     const long arow = g.row_gather ? g.row_gather[m] : m;
     aptr[i] = g.A + arow * (long)g.lda + scol;
-    wptr[i] = g.W + (long)(n0 + srow + 32 * i) * g.ldw + scol;
+    int wn_row = n0 + srow + 32 * i;                               // N need not fill the last tile: rows past N are
+    wn_row = wn_row < g.N ? wn_row : g.N - 1;                      // clamped here and never stored (epilogue guard)
+    wptr[i] = g.W + (long)wn_row * g.ldw + scol;
   }
 
   f32x16 acc[2][2];
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int n = n0 + wn * 64 + jn * 32 + 8 * g4 + 4 * hi;
+        if (n >= g.N) continue;                                      // N % 4 == 0: a float4 is all in or all out
         f32x4 v = {acc[i][jn][4 * g4], acc[i][jn][4 * g4 + 1], acc[i][jn][4 * g4 + 2], acc[i][jn][4 * g4 + 3]};
         if (g.bias) {
           const f32x4 bi = *reinterpret_cast<const f32x4*>(g.bias + n);
@@ -137,6 +140,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         } else if (g.act == ACT_GELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        } else if (g.act == ACT_ELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : expm1f(v[e]);
         }
         if (g.colscale) {
           const f32x4 cs = *reinterpret_cast<const f32x4*>(g.colscale + n);
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 }
 
 void launch_gemm_f32(const GemmArgs& g, hipStream_t s) {
-  const int tiles = ((g.M + BM - 1) / BM) * (g.N / BN);
+  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   if (tiles <= 0) return;
   hipLaunchKernelGGL(gemm_f32_kernel, dim3(tiles), dim3(256), 0, s, g);
 }

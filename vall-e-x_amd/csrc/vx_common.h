@@ -20,11 +20,11 @@ constexpr float LN_EPS = 1e-5f;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_ELU = 3 };
 
 // ---- big fp32 MFMA GEMM (gemm_f32.hip) -------------------------------------------------------
 // C[m][n] = resid[m][n] + colscale[n] * act(sum_k A[m][k] * W[n][k] + bias[n]),  m<M, n<N
-// N % 128 == 0, K % 32 == 0, all leading dims % 4 == 0; A must be readable for rows < M.
+// N % 4 == 0, K % 32 == 0, all leading dims % 4 == 0; A must be readable for rows < M.
 struct GemmArgs {
   const float* A; int lda;
   const float* W; int ldw;
@@ -120,6 +120,14 @@ struct SampleArgs {
 void launch_dec_sample(const SampleArgs& a, hipStream_t s);
 void launch_dec_force_token(const int* tok, int* cur_tok, int* cur_pos, int* ctx_len, int* n_gen, int* gen,
                             int gen_stride, const int* active, int batch, hipStream_t s);
+
+// ---- EnCodec SEANet decoder glue (encodec.hip) ----------------------------------------------------------------
+void launch_im2col_seq(const float* x, int C, int k, int mode, int elu, const int* seq_off, const int* seq_len, int R,
+                       float* out, int ldo, int batch, long max_rows, hipStream_t s);
+void launch_lstm_cell(const float* part, int splitk, const float* xg, const int* seq_off, const int* seq_len, int t,
+                      float* cstate, float* hp, float* y, const float* skip, int batch, hipStream_t s);
+void launch_final_conv(const float* x, const float* w, const float* bias, const int* seq_off, const int* seq_len, int R,
+                       float* audio, long audio_stride, int batch, long max_rows, hipStream_t s);
 
 // ---- Vocos head (vocos.hip) --------------------------------------------------------------------
 void launch_codebook_sum(const int* codes, const float* codebook, float* feat, int rows, hipStream_t s);

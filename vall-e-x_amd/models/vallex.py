@@ -98,6 +98,7 @@ class VALLE:
         self.language_ID = {"en": 0, "zh": 1, "ja": 2}          # models/vallex.py:439-443
         self._sd: Optional[Dict[str, np.ndarray]] = None
         self._vocos_sd: Optional[Dict[str, np.ndarray]] = None
+        self._encodec_sd: Optional[Dict[str, np.ndarray]] = None
         self._engine: Optional[Engine] = None
         self._device_id = 0
         self.engine_opts = dict(max_batch=int(kwargs.get("engine_max_batch", 32)),
@@ -136,6 +137,14 @@ class VALLE:
         self._engine = None
         return self
 
+    def load_encodec_state_dict(self, state_dict):
+        """Weights of `EncodecModel.encodec_model_24khz()` (data/tokenizer.py:71-73): encodec-package, transformers-port or
+        canonical key names; only the RVQ codebooks and the SEANet decoder are used."""
+        from ..data.tokenizer import canonical_encodec_state_dict
+        self._encodec_sd = canonical_encodec_state_dict(state_dict)
+        self._engine = None
+        return self
+
     # ---- engine ------------------------------------------------------------------------------------------------
     @property
     def engine(self) -> Engine:
@@ -144,7 +153,7 @@ class VALLE:
                 raise RuntimeError("load_state_dict() first")
             o = self.engine_opts
             eng = Engine(self._device_id, self.num_layers, o["max_batch"], o["max_text"], o["max_prompt"], o["max_new"],
-                         o["use_graph"], self._vocos_sd is not None, o["debug_taps"])
+                         o["use_graph"], self._vocos_sd is not None, o["debug_taps"], self._encodec_sd is not None)
             for k, v in self._sd.items():
                 eng.load_tensor(k, v)
             tmax = o["max_text"] + o["max_prompt"] + o["max_new"] + 16
@@ -152,6 +161,9 @@ class VALLE:
             if self._vocos_sd is not None:
                 for k, v in self._vocos_sd.items():
                     eng.load_tensor("vocos." + k, v)
+            if self._encodec_sd is not None:
+                for k, v in self._encodec_sd.items():
+                    eng.load_tensor("encodec." + k, v)
             eng.finalize()
             self._engine = eng
         return self._engine
