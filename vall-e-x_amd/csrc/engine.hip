@@ -3,6 +3,7 @@
 // utils/generation.py:148-150; every hot op is a hand-written gfx950 kernel from the sibling .hip files.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -28,6 +29,7 @@ struct Tensor {
 struct LayerW {
   const float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b, *n1_w, *n1_b, *n2_w, *n2_b;
   float *in_wp = nullptr, *out_wp = nullptr, *l1_wp = nullptr, *l2_wp = nullptr;   // packed decode images (AR only)
+  unsigned short *in_w3 = nullptr, *out_w3 = nullptr, *l1_w3 = nullptr, *l2_w3 = nullptr;   // 3 bf16 planes [3][N][K]
 };
 
 struct ProfClass {
@@ -66,6 +68,10 @@ struct vx_ctx {
   int Tmax = 0;                    // KV rows per (row, head)
   long Mmax = 0;                   // packed rows of a micro-batch on the full-sequence paths
 
+  // bf16x3 GEMM path (default) for the transformer projections of prefill / NAR; VX_GEMM_F32=1 keeps the fp32 MFMA
+  bool x3 = true;
+  unsigned short* fa3 = nullptr;   // activation planes [3][M][K<=4096]
+  unsigned short* pred_w3[N_Q - 1] = {};
   // full-sequence arena
   float *fx = nullptr, *fxn = nullptr, *fqkv = nullptr, *fatt = nullptr, *fffn = nullptr, *fyemb = nullptr,
         *flogits = nullptr;
@@ -222,26 +228,40 @@ void gemm(vx_ctx* c, const float* A, int lda, const float* Wt, int ldw, const fl
   launch_gemm_f32(g, c->stream);
 }
 
+// transformer projection: bf16x3 on the bf16 matrix cores (default) or the fp32 MFMA kernel
+void proj(vx_ctx* c, const float* A, int lda, const float* Wf, const unsigned short* W3, const float* bias,
+          const float* resid, int ldr, float* C, int ldc, long M, int N, int K, int act, const int* gather = nullptr) {
+  if (!c->x3 || !W3) {
+    gemm(c, A, lda, Wf, K, bias, resid, ldr, nullptr, C, ldc, M, N, K, act, gather);
+    return;
+  }
+  launch_split3(A, lda, M, K, gather, c->fa3, (long)M * K, c->stream);
+  GemmX3Args g{};
+  g.A = c->fa3; g.a_plane = (long)M * K; g.W = W3; g.w_plane = (long)N * K; g.bias = bias; g.resid = resid; g.ldr = ldr;
+  g.colscale = nullptr; g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.act = act;
+  ProfScope ps(c, 2);
+  if (c->prof_on) c->prof[2].bytes += 2.0 * (double)M * N * K;
+  launch_gemm_bf16x3(g, c->stream);
+}
+
 // one pre-norm block on packed rows (modules/transformer.py:296-302 / :337-347) -- shared by AR prefill and NAR
 int full_layer(vx_ctx* c, const LayerW& L, long M, const int* seq_off, const int* seq_len, const int* prefix_len,
                int batch, int max_len, const float* ada1, const float* ada2, float* kcl, float* vcl,
                const int* row_b, const int* row_t, double attn_flops) {
   launch_layernorm(c->fx, D_MODEL, c->fxn, D_MODEL, (int)M, D_MODEL, LN_EPS, L.n1_w, L.n1_b, ada1,
                    ada1 ? ada1 + D_MODEL : nullptr, c->stream);
-  gemm(c, c->fxn, D_MODEL, L.in_w, D_MODEL, L.in_b, nullptr, 0, nullptr, c->fqkv, 3 * D_MODEL, M, 3 * D_MODEL, D_MODEL,
-       ACT_NONE);
+  proj(c, c->fxn, D_MODEL, L.in_w, L.in_w3, L.in_b, nullptr, 0, c->fqkv, 3 * D_MODEL, M, 3 * D_MODEL, D_MODEL, ACT_NONE);
   if (kcl) launch_kv_scatter(c->fqkv, row_b, row_t, (int)M, kcl, vcl, c->Tmax, c->stream);
   {
     ProfScope ps(c, 3);
     if (c->prof_on) c->prof[3].bytes += attn_flops;
     launch_attn_full(c->fqkv, c->fatt, seq_off, seq_len, prefix_len, batch, max_len, c->stream);
   }
-  gemm(c, c->fatt, D_MODEL, L.out_w, D_MODEL, L.out_b, c->fx, D_MODEL, nullptr, c->fx, D_MODEL, M, D_MODEL, D_MODEL,
-       ACT_NONE);
+  proj(c, c->fatt, D_MODEL, L.out_w, L.out_w3, L.out_b, c->fx, D_MODEL, c->fx, D_MODEL, M, D_MODEL, D_MODEL, ACT_NONE);
   launch_layernorm(c->fx, D_MODEL, c->fxn, D_MODEL, (int)M, D_MODEL, LN_EPS, L.n2_w, L.n2_b, ada2,
                    ada2 ? ada2 + D_MODEL : nullptr, c->stream);
-  gemm(c, c->fxn, D_MODEL, L.l1_w, D_MODEL, L.l1_b, nullptr, 0, nullptr, c->fffn, D_FF, M, D_FF, D_MODEL, ACT_RELU);
-  gemm(c, c->fffn, D_FF, L.l2_w, D_FF, L.l2_b, c->fx, D_MODEL, nullptr, c->fx, D_MODEL, M, D_MODEL, D_FF, ACT_NONE);
+  proj(c, c->fxn, D_MODEL, L.l1_w, L.l1_w3, L.l1_b, nullptr, 0, c->fffn, D_FF, M, D_FF, D_MODEL, ACT_RELU);
+  proj(c, c->fffn, D_FF, L.l2_w, L.l2_w3, L.l2_b, c->fx, D_MODEL, c->fx, D_MODEL, M, D_MODEL, D_FF, ACT_NONE);
   return VX_OK;
 }
 
@@ -538,8 +558,8 @@ int nar_generate(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::vector
                      W(c, "nar_decoder.norm.norm.bias"), adaf, adaf + D_MODEL, c->stream);
     char nm[64];
     snprintf(nm, sizeof nm, "nar_predict_layers.%d.weight", st);
-    gemm(c, c->fxn, D_MODEL, W(c, nm), D_MODEL, nullptr, nullptr, 0, nullptr, c->flogits, AUDIO_VOCAB, sumT, AUDIO_VOCAB,
-         D_MODEL, ACT_NONE, mb.dev(o_gr));
+    proj(c, c->fxn, D_MODEL, W(c, nm), c->pred_w3[st], nullptr, nullptr, 0, c->flogits, AUDIO_VOCAB, sumT, AUDIO_VOCAB, D_MODEL,
+         ACT_NONE, mb.dev(o_gr));
     if (c->cfg.debug_taps && st == 0)
       if (int e = tap_store(c, "nar_logits0", c->flogits, (size_t)sumT * AUDIO_VOCAB)) return e;
     int* samples = c->imeta + o_samples + (long)st * sumT;
@@ -760,6 +780,27 @@ int vx_finalize_weights(vx_ctx* c) {
   if (const float* user_pe = W(c, "pe_table")) {
     const Tensor& t = c->w["pe_table"];
     if (t.shape.size() == 2 && t.shape[1] == d && t.shape[0] >= c->Tmax) { c->pe = const_cast<float*>(user_pe); c->pe_rows = (int)t.shape[0]; }
+  }
+
+  // ---- bf16 triple planes of every transformer projection used on the full-sequence paths ----
+  if (const char* ev = getenv("VX_GEMM_F32")) c->x3 = !(ev[0] == '1');
+  if (c->x3) {
+    auto split_w = [&](const float* Wt, int N, int K, unsigned short** out) -> int {
+      if (int e2 = dev_alloc(c, out, (size_t)3 * N * K, false)) return e2;
+      launch_split3(Wt, K, N, K, nullptr, *out, (long)N * K, c->stream);
+      return VX_OK;
+    };
+    for (int which = 0; which < 2; ++which)
+      for (int l = 0; l < NL; ++l) {
+        LayerW& L = which ? c->nar[l] : c->ar[l];
+        if ((e = split_w(L.in_w, 3 * d, d, &L.in_w3))) return e;
+        if ((e = split_w(L.out_w, d, d, &L.out_w3))) return e;
+        if ((e = split_w(L.l1_w, f, d, &L.l1_w3))) return e;
+        if ((e = split_w(L.l2_w, d, f, &L.l2_w3))) return e;
+      }
+    for (int j = 0; j < N_Q - 1; ++j)
+      if ((e = split_w(W(c, "nar_predict_layers." + std::to_string(j) + ".weight"), AUDIO_VOCAB, d, &c->pred_w3[j]))) return e;
+    if ((e = dev_alloc(c, &c->fa3, (size_t)3 * (c->Mmax + 128) * f, false))) return e;
   }
 
   // ---- packed decode images of the AR stack ----

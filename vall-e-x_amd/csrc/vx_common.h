@@ -38,6 +38,20 @@ struct GemmArgs {
 };
 void launch_gemm_f32(const GemmArgs& g, hipStream_t s);
 
+// ---- fp32-accurate GEMM on the bf16 matrix cores (gemm_bf16x3.hip) ------------------------------------------
+// operands are three bf16 planes [3][rows][K] (x = x1 + x2 + x3); same epilogue contract as GemmArgs.  K % 32 == 0.
+struct GemmX3Args {
+  const unsigned short* A; long a_plane;   // [3][M][K], plane stride in elements
+  const unsigned short* W; long w_plane;   // [3][N][K]
+  const float* bias; const float* resid; int ldr; const float* colscale;
+  float* C; int ldc;
+  int M, N, K;
+  int act;
+};
+void launch_gemm_bf16x3(const GemmX3Args& g, hipStream_t s);
+void launch_split3(const float* x, int ldx, long rows, int K, const int* gather, unsigned short* planes,
+                   long plane_stride, hipStream_t s);
+
 // ---- row-wise ops (rows.hip) --------------------------------------------------------------------
 // y = (LN(x) * g + b) [* ada_w + ada_b]; any of g/b/ada_* may be null.  C in {1024, 384}.
 void launch_layernorm(const float* x, int ldx, float* y, int ldy, int rows, int C, float eps, const float* g,
