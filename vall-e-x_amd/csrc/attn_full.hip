@@ -37,11 +37,18 @@ __device__ __forceinline__ float exp_bf(float x) {
 __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                           const int* __restrict__ seq_off,
                                                           const int* __restrict__ seq_len,
-                                                          const int* __restrict__ prefix_len) {
+                                                          const int* __restrict__ prefix_len, int nqb) {
   __shared__ __attribute__((aligned(16))) float Ks[2][KT * K_LD];
   __shared__ __attribute__((aligned(16))) float Vs[2][KT * V_LD];
 
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QB;
+  // XCD-aware work order.  Workgroup ids are dealt round-robin to the 8 XCDs (id % 8), each with a private L2, and the
+  // K/V of one (sequence, head) are re-read by every query block of that unit.  Units are therefore dealt 8 at a time
+  // (one per XCD) and a unit's query blocks take the ids base + 8*q + (u % 8): same XCD, back to back, so K/V is fetched
+  // into that L2 once instead of once per query block (measured L2 hit rate of the naive order: 23 %).
+  const int id = blockIdx.x, per8 = 8 * nqb;
+  const int grp = id / per8, rem = id - grp * per8;
+  const int u = grp * 8 + (rem & 7);
+  const int b = u / N_HEAD, h = u - b * N_HEAD, q0 = (rem >> 3) * QB;
   const int len = seq_len[b];
   if (q0 >= len) return;
   const long row0 = seq_off[b];
@@ -210,8 +217,9 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
 void launch_attn_full(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
                       int batch, int max_len, hipStream_t s) {
   if (batch <= 0 || max_len <= 0) return;
-  dim3 grid((max_len + QB - 1) / QB, N_HEAD, batch);
-  hipLaunchKernelGGL(attn_full_kernel, grid, dim3(256), 0, s, qkv, out, seq_off, seq_len, prefix_len);
+  const int nqb = (max_len + QB - 1) / QB;                   // batch * N_HEAD is a multiple of 8 (16 heads)
+  hipLaunchKernelGGL(attn_full_kernel, dim3(nqb * N_HEAD * batch), dim3(256), 0, s, qkv, out, seq_off, seq_len,
+                     prefix_len, nqb);
 }
 
 }  // namespace vx

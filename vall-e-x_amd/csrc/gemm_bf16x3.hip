@@ -10,8 +10,8 @@
 // 2.67x more matrix throughput for the NAR / prefill projections, which are 45 % of end-to-end time.
 //
 // Operands arrive pre-split as three bf16 planes [3][rows][K] (weights once at load, activations by split3_kernel or the
-// producer's epilogue).  Tile 128 x 128 x 32, 4 waves as 2 x 2, 2 x 2 MFMA tiles per wave; LDS rows padded to 80 B so the
-// ds_read_b128 fragment reads are conflict-free; the transposed product (A operand = W) gives each lane one output row
+// producer's epilogue).  Tile 128 x 128 x 32, 4 waves as 2 x 2, 2 x 2 MFMA tiles per wave; LDS rows of 64 B with the 16-B chunk index
+// XOR-swizzled by (row/4)%4 so both the staging ds_write_b128 and the fragment ds_read_b128 are conflict-free; the transposed product (A operand = W) gives each lane one output row
 // and float4 runs of n for the epilogue, as in gemm_f32.hip.
 #include <algorithm>
 
@@ -22,7 +22,7 @@ namespace vx {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int XB_M = 128, XB_N = 128, XB_K = 32, XB_LD = 80;     // LDS row stride in bytes (64 B of data + 16 B pad)
+constexpr int XB_M = 128, XB_N = 128, XB_K = 32, XB_LD = 64;     // LDS row stride in bytes: unpadded, XOR-swizzled chunks
 
 __device__ __forceinline__ float gelu_erf2(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmX3Args g) {
     n = n < g.N ? n : g.N - 1;
     aptr[i] = g.A + (long)m * g.K + ch * 8;
     wptr[i] = g.W + (long)n * g.K + ch * 8;
-    lds_off[i] = row * XB_LD + ch * 16;
+    lds_off[i] = row * XB_LD + ((ch ^ ((row >> 2) & 3)) * 16);   // 16-B chunk index XOR (row/4)%4: conflict-free for
+                                                                  // the ds_write_b128 here AND the ds_read_b128 below
   }
 
   f32x16 acc[2][2];
@@ -152,13 +153,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmX3Args g) {
       for (int p = 0; p < 3; ++p)
 #pragma unroll
         for (int jn = 0; jn < 2; ++jn)
-          w[p][jn] = *reinterpret_cast<const bf16x8*>(&Ws[p][(wn * 64 + jn * 32 + l31) * XB_LD + (2 * s + hi) * 16]);
+          w[p][jn] = *reinterpret_cast<const bf16x8*>(&Ws[p][(wn * 64 + jn * 32 + l31) * XB_LD + (((2 * s + hi) ^ ((l31 >> 2) & 3)) * 16)]);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         bf16x8 a[3];                                             // only one A row-tile live at a time (VGPR budget)
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-          a[p] = *reinterpret_cast<const bf16x8*>(&As[p][(wm * 64 + i * 32 + l31) * XB_LD + (2 * s + hi) * 16]);
+          a[p] = *reinterpret_cast<const bf16x8*>(&As[p][(wm * 64 + i * 32 + l31) * XB_LD + (((2 * s + hi) ^ ((l31 >> 2) & 3)) * 16)]);
         // transposed product (A operand = W rows): small terms first, then the leading one
 #pragma unroll
         for (int jn = 0; jn < 2; ++jn) {
