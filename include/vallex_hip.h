@@ -137,6 +137,10 @@ int vx_prof_reset(vx_ctx* ctx);
  * timed on ROCm 7.2).  which 0: dec_attn with every row at context prefill_len + gen_offset; which 1: the four
  * weight-streaming GEMMs of a layer.  avg_us = per launch; algo_bytes = algorithmic bytes per launch. */
 int vx_bench_kernel(vx_ctx* ctx, int32_t which, int32_t reps, int32_t gen_offset, double* avg_us, double* algo_bytes);
+/* kernel-development aid: time one full-sequence GEMM kernel (0 fp32 MFMA, 1 bf16x3) on scratch data and
+ * report its max abs difference to the fp32-MFMA kernel.  Not used by the product path. */
+int vx_bench_gemm(vx_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t kernel, int32_t reps, double* avg_us,
+                  double* max_abs_diff);
 /* counters of the last vx_infer: AR steps run, generated frames, AR / NAR wall milliseconds (stream-synchronised) */
 int vx_last_stats(vx_ctx* ctx, int64_t* ar_steps, int64_t* frames, double* ar_ms, double* nar_ms);
 

@@ -1,0 +1,17 @@
+#!/usr/bin/env python
+"""Kernel-development aid: time the full-sequence GEMM kernels on the NAR shapes (M = 31616 packed rows).
+   python tools/gemm_bench.py            # on an MI355X"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vallex_amd  # noqa: E402
+
+eng = vallex_amd.Engine(num_layers=1, max_batch=1, max_text=8, max_prompt=8, max_new=8, with_vocos=False)
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 31616
+for (N, K) in ((3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)):
+    row = [f"N={N:5d} K={K:5d}"]
+    for k, name in ((0, "f32"), (1, "x3")):
+        us, md = eng.bench_gemm(M, N, K, k, 5)
+        row.append(f"{name}: {us:8.1f} us {2.0 * M * N * K / us / 1e6:6.1f} TF diff {md:.2e}")
+    print("  |  ".join(row), flush=True)

@@ -1432,6 +1432,77 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
   return VX_OK;
 }
 
+// Stand-alone GEMM micro-benchmark on scratch buffers (kernel development aid; never on the product path):
+// kernel 0 = gemm_f32, 1 = gemm_bf16x3.  Reports the average launch time and the max abs
+// difference of the first 256 output rows against the fp32-MFMA kernel.
+int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, int32_t reps, double* avg_us,
+                  double* max_abs_diff) {
+  if (!c || M <= 0 || N <= 0 || K <= 0 || K % 32 || N % 4 || reps <= 0 || !avg_us || !max_abs_diff) return VX_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  float *A = nullptr, *Wt = nullptr, *C0 = nullptr, *C1 = nullptr;
+  unsigned short *A3 = nullptr, *W3 = nullptr;
+  auto cleanup = [&]() { for (void* p : {(void*)A, (void*)Wt, (void*)C0, (void*)C1, (void*)A3, (void*)W3}) if (p) (void)hipFree(p); };
+  hipError_t he;
+#define TRY(x) if ((he = (x)) != hipSuccess) { cleanup(); c->err = std::string(#x) + ": " + hipGetErrorString(he); return VX_EHIP; }
+  TRY(hipMalloc((void**)&A, (size_t)M * K * 4));
+  TRY(hipMalloc((void**)&Wt, (size_t)N * K * 4));
+  TRY(hipMalloc((void**)&C0, (size_t)M * N * 4));
+  TRY(hipMalloc((void**)&C1, (size_t)M * N * 4));
+  TRY(hipMalloc((void**)&A3, (size_t)3 * M * K * 2));
+  TRY(hipMalloc((void**)&W3, (size_t)3 * N * K * 2));
+  {
+    std::vector<float> h((size_t)std::max(M, N) * K);
+    unsigned long long st = 0x9E3779B97F4A7C15ull;
+    auto fill = [&](size_t n) { for (size_t i = 0; i < n; ++i) { st = st * 6364136223846793005ull + 1442695040888963407ull; h[i] = (float)((st >> 40) & 0xFFFFFF) / 8388608.0f - 1.0f; } };
+    fill((size_t)M * K);
+    TRY(hipMemcpy(A, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice));
+    fill((size_t)N * K);
+    TRY(hipMemcpy(Wt, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice));
+  }
+  GemmArgs g0{};
+  g0.A = A; g0.lda = K; g0.W = Wt; g0.ldw = K; g0.C = C0; g0.ldc = N; g0.M = M; g0.N = N; g0.K = K; g0.act = ACT_NONE;
+  launch_gemm_f32(g0, c->stream);
+  launch_split3(A, K, M, K, nullptr, A3, (long)M * K, c->stream);
+  launch_split3(Wt, K, N, K, nullptr, W3, (long)N * K, c->stream);
+  GemmX3Args gx{};
+  gx.A = A3; gx.a_plane = (long)M * K; gx.W = W3; gx.w_plane = (long)N * K; gx.C = C1; gx.ldc = N; gx.M = M; gx.N = N; gx.K = K;
+  gx.act = ACT_NONE;
+  GemmArgs g1 = g0;
+  g1.C = C1;
+  auto run = [&]() {
+    if (kernel == 0) launch_gemm_f32(g1, c->stream);
+    else launch_gemm_bf16x3(gx, c->stream);
+  };
+  run();
+  hipEvent_t e0, e1;
+  TRY(hipEventCreate(&e0));
+  TRY(hipEventCreate(&e1));
+  TRY(hipEventRecord(e0, c->stream));
+  for (int r = 0; r < reps; ++r) run();
+  TRY(hipEventRecord(e1, c->stream));
+  TRY(hipEventSynchronize(e1));
+  float ms = 0;
+  TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_us = (double)ms * 1e3 / reps;
+  const int rows = std::min(M, 256);
+  std::vector<float> h0((size_t)rows * N), h1((size_t)rows * N);
+  TRY(hipMemcpy(h0.data(), C0, h0.size() * 4, hipMemcpyDeviceToHost));
+  TRY(hipMemcpy(h1.data(), C1, h1.size() * 4, hipMemcpyDeviceToHost));
+  // also the LAST rows (tile tails)
+  double md = 0;
+  for (size_t i = 0; i < h0.size(); ++i) md = std::max(md, (double)fabsf(h0[i] - h1[i]));
+  TRY(hipMemcpy(h0.data(), C0 + (size_t)(M - rows) * N, h0.size() * 4, hipMemcpyDeviceToHost));
+  TRY(hipMemcpy(h1.data(), C1 + (size_t)(M - rows) * N, h1.size() * 4, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < h0.size(); ++i) md = std::max(md, (double)fabsf(h0[i] - h1[i]));
+  *max_abs_diff = md;
+#undef TRY
+  cleanup();
+  HIPCHK(hipGetLastError());
+  return VX_OK;
+}
+
 int vx_last_stats(vx_ctx* c, int64_t* ar_steps, int64_t* frames, double* ar_ms, double* nar_ms) {
   if (!c) return VX_EINVAL;
   if (ar_steps) *ar_steps = c->st_steps;
