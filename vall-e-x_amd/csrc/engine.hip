@@ -1471,7 +1471,8 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
   g1.C = C1;
   auto run = [&]() {
     if (kernel == 0) launch_gemm_f32(g1, c->stream);
-    else launch_gemm_bf16x3(gx, c->stream);
+    else if (kernel == 1) launch_gemm_bf16x3(gx, c->stream);
+    else launch_gemm_bf16x3_probe(gx, kernel - 10, c->stream);      // 11 / 12 / 13: timing probes
   };
   run();
   hipEvent_t e0, e1;

@@ -9,8 +9,8 @@
 // (32 cycles each, 16 k) = 192 cycles per 32x32x16 block of work, against 8 x 64 = 512 cycles on v_mfma_f32_32x32x2_f32:
 // 2.67x more matrix throughput for the NAR / prefill projections, which are 45 % of end-to-end time.
 //
-// Operands arrive pre-split as three bf16 planes [3][rows][K] (weights once at load, activations by split3_kernel or the
-// producer's epilogue).  Tile 128 x 128 x 32, 4 waves as 2 x 2, 2 x 2 MFMA tiles per wave; LDS rows of 64 B with the 16-B chunk index
+// Operands arrive pre-split as three bf16 planes in K-tile-major order [3][K/32][rows][32] (weights once at load,
+// activations by split3_kernel), so a staged 128 x 32 tile is one contiguous 8 KiB run of full cache lines.  Tile 128 x 128 x 32, 4 waves as 2 x 2, 2 x 2 MFMA tiles per wave; LDS rows of 64 B with the 16-B chunk index
 // XOR-swizzled by (row/4)%4 so both the staging ds_write_b128 and the fragment ds_read_b128 are conflict-free; the transposed product (A operand = W) gives each lane one output row
 // and float4 runs of n for the epilogue, as in gemm_f32.hip.
 #include <algorithm>
@@ -32,14 +32,19 @@ __device__ __forceinline__ float gelu_erf2(float x) { return 0.5f * x * (1.0f + 
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, int ldx, long rows, int K,
                                                      const int* __restrict__ gather, unsigned short* __restrict__ planes,
                                                      long plane_stride) {
-  const int per_row = K / 8;
-  const long total = rows * per_row;
+  // Output layout is K-TILE-MAJOR: plane[kt][row][32]  (kt = k / 32).  The GEMM stages 128 rows x 32 k per plane and
+  // K tile; with this layout that is ONE contiguous 8 KiB run (full 128-B lines, 1 KiB per wave load) instead of 128
+  // half-used lines 2*K bytes apart -- the row-major image made the kernel L2-bandwidth bound (each line was fetched
+  // twice, once per K tile).  Work item = (kt, row, 16-byte chunk), chunk fastest, so writes are contiguous too.
+  const long total = (long)(K / 32) * rows * 4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long r = i / per_row;
-    const int c = (int)(i - r * per_row) * 8;
+    const int ch = (int)(i & 3);
+    const long rr = i >> 2;
+    const long kt = rr / rows, r = rr - kt * rows;
     const long src = gather ? gather[r] : r;
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + src * ldx + c);
-    const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + src * ldx + c + 4);
+    const float* xp = x + src * ldx + kt * 32 + ch * 8;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(xp);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(xp + 4);
     float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
     bf16x8 p1, p2, p3;
 #pragma unroll
@@ -50,7 +55,7 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
       const float r2 = r1 - (float)a2;                         // exact
       p1[e] = a1; p2[e] = a2; p3[e] = (__bf16)r2;
     }
-    unsigned short* o = planes + r * (long)K + c;
+    unsigned short* o = planes + i * 8;                        // == ((kt * rows + r) * 32 + ch * 8)
     *reinterpret_cast<bf16x8*>(o) = p1;
     *reinterpret_cast<bf16x8*>(o + plane_stride) = p2;
     *reinterpret_cast<bf16x8*>(o + 2 * plane_stride) = p3;
@@ -68,6 +73,9 @@ void launch_split3(const float* x, int ldx, long rows, int K, const int* gather,
 // ---------------------------------------------------------------------------------------------------------------
 // C[m][n] = resid[m][n] + colscale[n] * act( sum_k A[m][k] W[n][k] + bias[n] ),  A, W given as 3 bf16 planes
 // ---------------------------------------------------------------------------------------------------------------
+// V = 0 product kernel.  Timing probes for tools/gemm_bench.py (results are meaningless): V = 1 no global loads / LDS
+// writes after the first tile; V = 2 no MFMAs; V = 3 no fragment reads after the first tile (MFMAs on stale registers).
+template <int V>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmX3Args g) {
   __shared__ __attribute__((aligned(16))) unsigned char As[3][XB_M * XB_LD];
   __shared__ __attribute__((aligned(16))) unsigned char Ws[3][XB_N * XB_LD];
@@ -102,8 +110,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmX3Args g) {
     m = m < g.M ? m : g.M - 1;
     int n = n0 + row;
     n = n < g.N ? n : g.N - 1;
-    aptr[i] = g.A + (long)m * g.K + ch * 8;
-    wptr[i] = g.W + (long)n * g.K + ch * 8;
+    aptr[i] = g.A + (long)m * XB_K + ch * 8;                    // k-tile-major planes: [kt][row][32]
+    wptr[i] = g.W + (long)n * XB_K + ch * 8;
     lds_off[i] = row * XB_LD + ((ch ^ ((row >> 2) & 3)) * 16);   // 16-B chunk index XOR (row/4)%4: conflict-free for
                                                                   // the ds_write_b128 here AND the ds_read_b128 below
   }
@@ -128,27 +136,30 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmX3Args g) {
   const int nk = g.K / XB_K;
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        *reinterpret_cast<u32x4*>(&As[p][lds_off[i]]) = ra[p][i];
-        *reinterpret_cast<u32x4*>(&Ws[p][lds_off[i]]) = rw[p][i];
-      }
-    __syncthreads();
-    if (kt + 1 < nk) {
+    if (V != 1 || kt == 0) {
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          ra[p][i] = *reinterpret_cast<const u32x4*>(aptr[i] + p * g.a_plane + (kt + 1) * XB_K);
-          rw[p][i] = *reinterpret_cast<const u32x4*>(wptr[i] + p * g.w_plane + (kt + 1) * XB_K);
+          *reinterpret_cast<u32x4*>(&As[p][lds_off[i]]) = ra[p][i];
+          *reinterpret_cast<u32x4*>(&Ws[p][lds_off[i]]) = rw[p][i];
+        }
+    }
+    __syncthreads();
+    if (V != 1 && kt + 1 < nk) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ra[p][i] = *reinterpret_cast<const u32x4*>(aptr[i] + p * g.a_plane + (long)(kt + 1) * g.M * XB_K);
+          rw[p][i] = *reinterpret_cast<const u32x4*>(wptr[i] + p * g.w_plane + (long)(kt + 1) * g.N * XB_K);
         }
     }
 #pragma unroll
     for (int s = 0; s < XB_K / 16; ++s) {
       // fragment of k-step s: lane supplies row (l31) and k = 16 s + 8 hi + 0..7  -> 16-byte chunk 2 s + hi of the row
       bf16x8 w[3][2];
+      if (V != 3 || kt == 0)
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -157,6 +168,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmX3Args g) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         bf16x8 a[3];                                             // only one A row-tile live at a time (VGPR budget)
+        if (V != 3 || kt == 0)
 #pragma unroll
         for (int p = 0; p < 3; ++p)
           a[p] = *reinterpret_cast<const bf16x8*>(&As[p][(wm * 64 + i * 32 + l31) * XB_LD + (((2 * s + hi) ^ ((l31 >> 2) & 3)) * 16)]);
@@ -164,6 +176,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmX3Args g) {
 #pragma unroll
         for (int jn = 0; jn < 2; ++jn) {
           f32x16 c = acc[i][jn];
+          if (V == 2) {
+            c[0] += (float)(a[0][0] + a[1][1] + a[2][2]) + (float)(w[0][jn][0] + w[1][jn][1] + w[2][jn][2]);
+            acc[i][jn] = c;
+            continue;
+          }
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2][jn], a[0], c, 0, 0, 0);   // w3 a1
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0][jn], a[2], c, 0, 0, 0);   // w1 a3
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1][jn], a[1], c, 0, 0, 0);   // w2 a2
@@ -219,7 +236,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmX3Args g) {
 void launch_gemm_bf16x3(const GemmX3Args& g, hipStream_t s) {
   const int tiles = ((g.M + XB_M - 1) / XB_M) * ((g.N + XB_N - 1) / XB_N);
   if (tiles <= 0) return;
-  hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3(tiles), dim3(256), 0, s, g);
+  hipLaunchKernelGGL(gemm_bf16x3_kernel<0>, dim3(tiles), dim3(256), 0, s, g);
+}
+
+void launch_gemm_bf16x3_probe(const GemmX3Args& g, int variant, hipStream_t s) {
+  const int tiles = ((g.M + XB_M - 1) / XB_M) * ((g.N + XB_N - 1) / XB_N);
+  if (variant == 1) hipLaunchKernelGGL(gemm_bf16x3_kernel<1>, dim3(tiles), dim3(256), 0, s, g);
+  else if (variant == 2) hipLaunchKernelGGL(gemm_bf16x3_kernel<2>, dim3(tiles), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(gemm_bf16x3_kernel<3>, dim3(tiles), dim3(256), 0, s, g);
 }
 
 }  // namespace vx

@@ -39,7 +39,8 @@ struct GemmArgs {
 void launch_gemm_f32(const GemmArgs& g, hipStream_t s);
 
 // ---- fp32-accurate GEMM on the bf16 matrix cores (gemm_bf16x3.hip) ------------------------------------------
-// operands are three bf16 planes [3][rows][K] (x = x1 + x2 + x3); same epilogue contract as GemmArgs.  K % 32 == 0.
+// operands are three bf16 planes (x = x1 + x2 + x3), each K-tile-major [K/32][rows][32]; same epilogue contract as
+// GemmArgs.  K % 32 == 0.
 struct GemmX3Args {
   const unsigned short* A; long a_plane;   // [3][M][K], plane stride in elements
   const unsigned short* W; long w_plane;   // [3][N][K]
@@ -49,6 +50,7 @@ struct GemmX3Args {
   int act;
 };
 void launch_gemm_bf16x3(const GemmX3Args& g, hipStream_t s);
+void launch_gemm_bf16x3_probe(const GemmX3Args& g, int variant, hipStream_t s);   // timing probes (tools/gemm_bench.py)
 void launch_split3(const float* x, int ldx, long rows, int K, const int* gather, unsigned short* planes,
                    long plane_stride, hipStream_t s);
 
