@@ -46,7 +46,7 @@ class vx_sampling(C.Structure):
 # every symbol include/vallex_hip.h declares (tests/test_abi.py checks the library exports exactly these)
 SYMBOLS = ["vx_create", "vx_destroy", "vx_last_error", "vx_synchronize", "vx_load_tensor", "vx_finalize_weights",
            "vx_infer", "vx_vocos_decode", "vx_encodec_decode", "vx_ar_prefill", "vx_ar_logits", "vx_ar_step", "vx_nar", "vx_read_tap",
-           "vx_prof_enable", "vx_prof_get", "vx_prof_reset", "vx_bench_kernel", "vx_bench_gemm", "vx_last_stats"]
+           "vx_prof_enable", "vx_prof_get", "vx_prof_reset", "vx_bench_kernel", "vx_bench_gemm", "vx_bench_attn", "vx_last_stats"]
 
 _lib = None
 
@@ -85,6 +85,7 @@ def load_library() -> C.CDLL:
     lib.vx_prof_reset.argtypes = [ctx]
     lib.vx_bench_kernel.argtypes = [ctx, C.c_int32, C.c_int32, C.c_int32, P(C.c_double), P(C.c_double)]
     lib.vx_bench_gemm.argtypes = [ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P(C.c_double), P(C.c_double)]
+    lib.vx_bench_attn.argtypes = [ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P(C.c_double)]
     lib.vx_last_stats.argtypes = [ctx, P(C.c_int64), P(C.c_int64), P(C.c_double), P(C.c_double)]
     for name in SYMBOLS:
         fn = getattr(lib, name)
@@ -272,6 +273,11 @@ class Engine:
         us, md = C.c_double(), C.c_double()
         self._chk(self.lib.vx_bench_gemm(self.ctx, M, N, K, kernel, reps, C.byref(us), C.byref(md)))
         return us.value, md.value
+
+    def bench_attn(self, batch: int, length: int, causal: bool, variant: int, reps: int = 5):
+        us = C.c_double()
+        self._chk(self.lib.vx_bench_attn(self.ctx, batch, length, int(causal), variant, reps, C.byref(us)))
+        return us.value
 
     def last_stats(self):
         a, f, am, nm = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()

@@ -34,6 +34,9 @@ __device__ __forceinline__ float exp_bf(float x) {
   return fmaf(e, pl * LN2, e);
 }
 
+// V = 0 product kernel.  Timing probes (tools/attn_bench.py, results meaningless): V = 1 no K/V staging after the first two
+// tiles; V = 2 no MFMAs; V = 3 no softmax arithmetic.
+template <int V>
 __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                           const int* __restrict__ seq_off,
                                                           const int* __restrict__ seq_len,
@@ -150,9 +153,15 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
         kfA = *reinterpret_cast<const f32x4*>(&Ks[nxt][l31 * K_LD + (2 * cp) * 8 + hi * 4]);
         kfB = *reinterpret_cast<const f32x4*>(&Ks[nxt][l31 * K_LD + (2 * cp + 1) * 8 + hi * 4]);
       }
-      sA = __builtin_amdgcn_mfma_f32_32x32x2f32(kfA[j], qreg[(2 * cp) * 4 + j], sA, 0, 0, 0);
-      sA = __builtin_amdgcn_mfma_f32_32x32x2f32(kfB[j], qreg[(2 * cp + 1) * 4 + j], sA, 0, 0, 0);
-      if (i < 4) {                                             // steps 0-3: visibility mask, 4 keys per step
+      if (V == 2) {
+        sA[0] += kfA[j] * qreg[(2 * cp) * 4 + j] + kfB[j] * qreg[(2 * cp + 1) * 4 + j];
+      } else {
+        sA = __builtin_amdgcn_mfma_f32_32x32x2f32(kfA[j], qreg[(2 * cp) * 4 + j], sA, 0, 0, 0);
+        sA = __builtin_amdgcn_mfma_f32_32x32x2f32(kfB[j], qreg[(2 * cp + 1) * 4 + j], sA, 0, 0, 0);
+      }
+      if (V == 3) {
+        // probe: no softmax work at all
+      } else if (i < 4) {                                      // steps 0-3: visibility mask, 4 keys per step
 #pragma unroll
         for (int r = 4 * i; r < 4 * i + 4; ++r) {
           const int kj = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -187,15 +196,20 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
       const int key = (r & 3) + 8 * (r >> 2) + 4 * hi;
       const float v0 = Vs[cur][key * V_LD + l31];
       const float v1 = Vs[cur][key * V_LD + 32 + l31];
-      o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s_cur[r], o[0], 0, 0, 0);
-      o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s_cur[r], o[1], 0, 0, 0);
+      if (V == 2) {
+        o[0][r] += v0 * s_cur[r];
+        o[1][r] += v1 * s_cur[r];
+      } else {
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s_cur[r], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s_cur[r], o[1], 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) s_cur[r] = sA[r];
     __syncthreads();                                           // everyone is done reading buffer `cur`
-    if (t + 2 < ntiles) stage_write(cur);                      // registers hold tile t+2
+    if (V != 1 && t + 2 < ntiles) stage_write(cur);            // registers hold tile t+2
     __syncthreads();
-    if (t + 3 < ntiles) issue((t + 3) * KT);
+    if (V != 1 && t + 3 < ntiles) issue((t + 3) * KT);
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -218,8 +232,17 @@ void launch_attn_full(const float* qkv, float* out, const int* seq_off, const in
                       int batch, int max_len, hipStream_t s) {
   if (batch <= 0 || max_len <= 0) return;
   const int nqb = (max_len + QB - 1) / QB;                   // batch * N_HEAD is a multiple of 8 (16 heads)
-  hipLaunchKernelGGL(attn_full_kernel, dim3(nqb * N_HEAD * batch), dim3(256), 0, s, qkv, out, seq_off, seq_len,
+  hipLaunchKernelGGL(attn_full_kernel<0>, dim3(nqb * N_HEAD * batch), dim3(256), 0, s, qkv, out, seq_off, seq_len,
                      prefix_len, nqb);
+}
+
+void launch_attn_full_probe(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
+                            int batch, int max_len, int variant, hipStream_t s) {
+  const int nqb = (max_len + QB - 1) / QB;
+  const dim3 grid(nqb * N_HEAD * batch), block(256);
+  if (variant == 1) hipLaunchKernelGGL(attn_full_kernel<1>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
+  else if (variant == 2) hipLaunchKernelGGL(attn_full_kernel<2>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
+  else hipLaunchKernelGGL(attn_full_kernel<3>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
 }
 
 }  // namespace vx

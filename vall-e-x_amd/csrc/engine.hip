@@ -1504,6 +1504,53 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
   return VX_OK;
 }
 
+// kernel-development aid: time attn_full (variant 0) or one of its probes (1 no staging, 2 no MFMA, 3 no softmax) on
+// random q|k|v for `batch` sequences of length `len`, unmasked (NAR) or prefix-LM with prefix = len/3 (causal != 0).
+int vx_bench_attn(vx_ctx* c, int32_t batch, int32_t len, int32_t causal, int32_t variant, int32_t reps, double* avg_us) {
+  if (!c || batch <= 0 || len <= 0 || reps <= 0 || !avg_us) return VX_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  const long M = (long)batch * len;
+  float *qkv = nullptr, *out = nullptr;
+  int* meta = nullptr;
+  auto cleanup = [&]() { for (void* p : {(void*)qkv, (void*)out, (void*)meta}) if (p) (void)hipFree(p); };
+  hipError_t he;
+#define TRY(x) if ((he = (x)) != hipSuccess) { cleanup(); c->err = std::string(#x) + ": " + hipGetErrorString(he); return VX_EHIP; }
+  TRY(hipMalloc((void**)&qkv, (size_t)M * 3 * D_MODEL * 4));
+  TRY(hipMalloc((void**)&out, (size_t)M * D_MODEL * 4));
+  TRY(hipMalloc((void**)&meta, (size_t)3 * batch * 4));
+  {
+    std::vector<float> h((size_t)M * 3 * D_MODEL);
+    unsigned long long st = 0x9E3779B97F4A7C15ull;
+    for (auto& v : h) { st = st * 6364136223846793005ull + 1442695040888963407ull; v = (float)((st >> 40) & 0xFFFFFF) / 8388608.0f - 1.0f; }
+    TRY(hipMemcpy(qkv, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    std::vector<int> m(3 * batch);
+    for (int i = 0; i < batch; ++i) { m[i] = i * len; m[batch + i] = len; m[2 * batch + i] = len / 3; }
+    TRY(hipMemcpy(meta, m.data(), m.size() * 4, hipMemcpyHostToDevice));
+  }
+  const int* pre = causal ? meta + 2 * batch : nullptr;
+  auto run = [&]() {
+    if (variant == 0) launch_attn_full(qkv, out, meta, meta + batch, pre, batch, len, c->stream);
+    else launch_attn_full_probe(qkv, out, meta, meta + batch, pre, batch, len, variant, c->stream);
+  };
+  run();
+  hipEvent_t e0, e1;
+  TRY(hipEventCreate(&e0));
+  TRY(hipEventCreate(&e1));
+  TRY(hipEventRecord(e0, c->stream));
+  for (int r = 0; r < reps; ++r) run();
+  TRY(hipEventRecord(e1, c->stream));
+  TRY(hipEventSynchronize(e1));
+  float ms = 0;
+  TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_us = (double)ms * 1e3 / reps;
+#undef TRY
+  cleanup();
+  HIPCHK(hipGetLastError());
+  return VX_OK;
+}
+
 int vx_last_stats(vx_ctx* c, int64_t* ar_steps, int64_t* frames, double* ar_ms, double* nar_ms) {
   if (!c) return VX_EINVAL;
   if (ar_steps) *ar_steps = c->st_steps;

@@ -85,6 +85,9 @@ void launch_gemv(const float* W, const float* e, const float* b, float* out, int
 void launch_attn_full(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
                       int batch, int max_len, hipStream_t s);
 
+void launch_attn_full_probe(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
+                            int batch, int max_len, int variant, hipStream_t s);   // timing probes (tools/attn_bench.py)
+
 // ---- AR decode step (decode.hip) ---------------------------------------------------------------
 // packed skinny-GEMM weight image: tiles of 32 n-rows x 8 k, lane-linear (see decode.hip)
 void launch_pack_weight(const float* W, int N, int K, float* Wp, int Npad, hipStream_t s);
