@@ -141,7 +141,8 @@ int vx_bench_kernel(vx_ctx* ctx, int32_t which, int32_t reps, int32_t gen_offset
  * report its max abs difference to the fp32-MFMA kernel.  Not used by the product path. */
 int vx_bench_gemm(vx_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t kernel, int32_t reps, double* avg_us,
                   double* max_abs_diff);
-int vx_bench_attn(vx_ctx* ctx, int32_t batch, int32_t len, int32_t causal, int32_t variant, int32_t reps, double* avg_us);
+int vx_bench_attn(vx_ctx* ctx, int32_t batch, int32_t len, int32_t causal, int32_t variant, int32_t reps, double* avg_us,
+                  double* max_diff);
 /* counters of the last vx_infer: AR steps run, generated frames, AR / NAR wall milliseconds (stream-synchronised) */
 int vx_last_stats(vx_ctx* ctx, int64_t* ar_steps, int64_t* frames, double* ar_ms, double* nar_ms);
 

@@ -85,7 +85,7 @@ def load_library() -> C.CDLL:
     lib.vx_prof_reset.argtypes = [ctx]
     lib.vx_bench_kernel.argtypes = [ctx, C.c_int32, C.c_int32, C.c_int32, P(C.c_double), P(C.c_double)]
     lib.vx_bench_gemm.argtypes = [ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P(C.c_double), P(C.c_double)]
-    lib.vx_bench_attn.argtypes = [ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P(C.c_double)]
+    lib.vx_bench_attn.argtypes = [ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P(C.c_double), P(C.c_double)]
     lib.vx_last_stats.argtypes = [ctx, P(C.c_int64), P(C.c_int64), P(C.c_double), P(C.c_double)]
     for name in SYMBOLS:
         fn = getattr(lib, name)
@@ -275,9 +275,10 @@ class Engine:
         return us.value, md.value
 
     def bench_attn(self, batch: int, length: int, causal: bool, variant: int, reps: int = 5):
-        us = C.c_double()
-        self._chk(self.lib.vx_bench_attn(self.ctx, batch, length, int(causal), variant, reps, C.byref(us)))
-        return us.value
+        """variant 0 fp32 kernel / 10 bf16x3 kernel (+1..3: timing probes); returns (avg_us, max |out - fp32 out| or -1)"""
+        us, md = C.c_double(), C.c_double()
+        self._chk(self.lib.vx_bench_attn(self.ctx, batch, length, int(causal), variant, reps, C.byref(us), C.byref(md)))
+        return us.value, md.value
 
     def last_stats(self):
         a, f, am, nm = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()

@@ -70,6 +70,7 @@ struct vx_ctx {
 
   // bf16x3 GEMM path (default) for the transformer projections of prefill / NAR; VX_GEMM_F32=1 keeps the fp32 MFMA
   bool x3 = true;
+  bool attn_x3 = true;                        // bf16x3 attention (attn_full_x3.hip); VX_ATTN_F32=1 keeps the fp32 MFMA kernel
   unsigned short* fa3 = nullptr;   // activation planes [3][M][K<=4096]
   unsigned short* pred_w3[N_Q - 1] = {};
   // full-sequence arena
@@ -255,7 +256,8 @@ int full_layer(vx_ctx* c, const LayerW& L, long M, const int* seq_off, const int
   {
     ProfScope ps(c, 3);
     if (c->prof_on) c->prof[3].bytes += attn_flops;
-    launch_attn_full(c->fqkv, c->fatt, seq_off, seq_len, prefix_len, batch, max_len, c->stream);
+    if (c->attn_x3) launch_attn_full_x3(c->fqkv, c->fatt, seq_off, seq_len, prefix_len, batch, max_len, 0, c->stream);
+    else launch_attn_full(c->fqkv, c->fatt, seq_off, seq_len, prefix_len, batch, max_len, c->stream);
   }
   proj(c, c->fatt, D_MODEL, L.out_w, L.out_w3, L.out_b, c->fx, D_MODEL, c->fx, D_MODEL, M, D_MODEL, D_MODEL, ACT_NONE);
   launch_layernorm(c->fx, D_MODEL, c->fxn, D_MODEL, (int)M, D_MODEL, LN_EPS, L.n2_w, L.n2_b, ada2,
@@ -784,6 +786,7 @@ int vx_finalize_weights(vx_ctx* c) {
 
   // ---- bf16 triple planes of every transformer projection used on the full-sequence paths ----
   if (const char* ev = getenv("VX_GEMM_F32")) c->x3 = !(ev[0] == '1');
+  if (const char* ev = getenv("VX_ATTN_F32")) c->attn_x3 = !(ev[0] == '1');
   if (c->x3) {
     auto split_w = [&](const float* Wt, int N, int K, unsigned short** out) -> int {
       if (int e2 = dev_alloc(c, out, (size_t)3 * N * K, false)) return e2;
@@ -1506,22 +1509,28 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
 
 // kernel-development aid: time attn_full (variant 0) or one of its probes (1 no staging, 2 no MFMA, 3 no softmax) on
 // random q|k|v for `batch` sequences of length `len`, unmasked (NAR) or prefix-LM with prefix = len/3 (causal != 0).
-int vx_bench_attn(vx_ctx* c, int32_t batch, int32_t len, int32_t causal, int32_t variant, int32_t reps, double* avg_us) {
+int vx_bench_attn(vx_ctx* c, int32_t batch, int32_t len, int32_t causal, int32_t variant, int32_t reps, double* avg_us,
+                  double* max_diff) {
+  // variant: 0 fp32 kernel, 1-3 its probes; 10 bf16x3 kernel, 11-13 its probes.  max_diff (optional) = max |out - out of
+  // the fp32 kernel| for the product variants (0 / 10), -1 for probes.
   if (!c || batch <= 0 || len <= 0 || reps <= 0 || !avg_us) return VX_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
   const long M = (long)batch * len;
-  float *qkv = nullptr, *out = nullptr;
+  float *qkv = nullptr, *out = nullptr, *ref = nullptr;
   int* meta = nullptr;
-  auto cleanup = [&]() { for (void* p : {(void*)qkv, (void*)out, (void*)meta}) if (p) (void)hipFree(p); };
+  auto cleanup = [&]() { for (void* p : {(void*)qkv, (void*)out, (void*)ref, (void*)meta}) if (p) (void)hipFree(p); };
   hipError_t he;
 #define TRY(x) if ((he = (x)) != hipSuccess) { cleanup(); c->err = std::string(#x) + ": " + hipGetErrorString(he); return VX_EHIP; }
   TRY(hipMalloc((void**)&qkv, (size_t)M * 3 * D_MODEL * 4));
   TRY(hipMalloc((void**)&out, (size_t)M * D_MODEL * 4));
+  TRY(hipMalloc((void**)&ref, (size_t)M * D_MODEL * 4));
   TRY(hipMalloc((void**)&meta, (size_t)3 * batch * 4));
   {
     std::vector<float> h((size_t)M * 3 * D_MODEL);
     unsigned long long st = 0x9E3779B97F4A7C15ull;
     for (auto& v : h) { st = st * 6364136223846793005ull + 1442695040888963407ull; v = (float)((st >> 40) & 0xFFFFFF) / 8388608.0f - 1.0f; }
+    // Q columns x4: scores of a few units instead of ~0.3, so the softmax is not nearly uniform
+    for (long r = 0; r < M; ++r) for (int k = 0; k < D_MODEL; ++k) h[(size_t)r * 3 * D_MODEL + k] *= 4.0f;
     TRY(hipMemcpy(qkv, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     std::vector<int> m(3 * batch);
     for (int i = 0; i < batch; ++i) { m[i] = i * len; m[batch + i] = len; m[2 * batch + i] = len / 3; }
@@ -1530,7 +1539,8 @@ int vx_bench_attn(vx_ctx* c, int32_t batch, int32_t len, int32_t causal, int32_t
   const int* pre = causal ? meta + 2 * batch : nullptr;
   auto run = [&]() {
     if (variant == 0) launch_attn_full(qkv, out, meta, meta + batch, pre, batch, len, c->stream);
-    else launch_attn_full_probe(qkv, out, meta, meta + batch, pre, batch, len, variant, c->stream);
+    else if (variant < 10) launch_attn_full_probe(qkv, out, meta, meta + batch, pre, batch, len, variant, c->stream);
+    else launch_attn_full_x3(qkv, out, meta, meta + batch, pre, batch, len, variant - 10, c->stream);
   };
   run();
   hipEvent_t e0, e1;
@@ -1545,6 +1555,22 @@ int vx_bench_attn(vx_ctx* c, int32_t batch, int32_t len, int32_t causal, int32_t
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   *avg_us = (double)ms * 1e3 / reps;
+  if (max_diff) {
+    *max_diff = -1.0;
+    if (variant == 0 || variant == 10) {
+      launch_attn_full(qkv, ref, meta, meta + batch, pre, batch, len, c->stream);
+      TRY(hipStreamSynchronize(c->stream));
+      std::vector<float> ho((size_t)M * D_MODEL), hr((size_t)M * D_MODEL);
+      TRY(hipMemcpy(ho.data(), out, ho.size() * 4, hipMemcpyDeviceToHost));
+      TRY(hipMemcpy(hr.data(), ref, hr.size() * 4, hipMemcpyDeviceToHost));
+      double md = 0;
+      for (size_t i = 0; i < ho.size(); ++i) {
+        const double d = std::fabs((double)ho[i] - (double)hr[i]);
+        md = (d > md || d != d) ? (d != d ? 1e30 : d) : md;
+      }
+      *max_diff = md;
+    }
+  }
 #undef TRY
   cleanup();
   HIPCHK(hipGetLastError());

@@ -85,6 +85,9 @@ void launch_gemv(const float* W, const float* e, const float* b, float* out, int
 void launch_attn_full(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
                       int batch, int max_len, hipStream_t s);
 
+// bf16x3 version (attn_full_x3.hip), the product path; variant 0 = product, 1-3 = timing probes
+void launch_attn_full_x3(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
+                         int batch, int max_len, int variant, hipStream_t s);
 void launch_attn_full_probe(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
                             int batch, int max_len, int variant, hipStream_t s);   // timing probes (tools/attn_bench.py)
 
