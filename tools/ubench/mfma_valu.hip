@@ -1,0 +1,86 @@
+// Micro-benchmark (kernel-development aid): how do the matrix pipe and the VALU of one gfx950 SIMD overlap?
+// Each wave runs ITER iterations of [1 x v_mfma_f32_32x32x16_bf16 | N x VALU op]; reports cycles per iteration (wall
+// time x nominal 2.4 GHz) for 1 and 2 waves per SIMD, several N and several VALU ops.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int ITER = 4000;
+
+// OP: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_cvt_pk_bf16_f32, 3 v_exp_f32, 4 v_cndmask (cmp+cndmask pair), 5 none
+template <int N, int OP, int CHAINS, bool MFMA>
+__global__ __launch_bounds__(256) void k(float* out, int iters) {
+  bf16x8 a, b;
+  for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(threadIdx.x * 0.001f + e); b[e] = (__bf16)(e * 0.5f); }
+  f32x16 c0 = {0}, c1 = {0};
+  float v[16];
+  for (int e = 0; e < 16; ++e) v[e] = threadIdx.x * 0.01f + e;
+  f32x2 pv[8];
+  for (int e = 0; e < 8; ++e) pv[e] = f32x2{v[e], v[e + 8]};
+  unsigned w[16];
+  for (int e = 0; e < 16; ++e) w[e] = threadIdx.x + e;
+  for (int it = 0; it < iters; ++it) {
+    if (MFMA) {
+      if (CHAINS == 1 || !(it & 1)) c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+      else c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      if (OP == 0) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(v[n & 15]));
+      if (OP == 1) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(pv[n & 7]));
+      if (OP == 2) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[n & 15]) : "v"(v[n & 15]), "v"(v[(n + 1) & 15]));
+      if (OP == 3) asm volatile("v_exp_f32 %0, %0" : "+v"(v[n & 15]));
+      if (OP == 4) asm volatile("v_cmp_lt_i32 vcc, %1, %2\n\ts_nop 1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(w[n & 15]) : "v"(w[(n + 1) & 15]), "v"(w[(n + 2) & 15]) : "vcc");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float acc = 0;
+  for (int e = 0; e < 16; ++e) acc += c0[e] + c1[e] + v[e] + (float)w[e];
+  for (int e = 0; e < 8; ++e) acc += pv[e][0] + pv[e][1];
+  out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+template <int N, int OP, int CHAINS, bool MFMA>
+void run(const char* name, float* out) {
+  for (int wps = 1; wps <= 2; ++wps) {
+    const int blocks = 256 * wps;                                // 4 waves per block -> wps waves per SIMD on 256 CUs
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k<N, OP, CHAINS, MFMA>), dim3(blocks), dim3(256), 0, 0, out, ITER);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((k<N, OP, CHAINS, MFMA>), dim3(blocks), dim3(256), 0, 0, out, ITER);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("%-28s N=%2d mfma=%d chains=%d waves/SIMD=%d : %7.1f cycles/iter/wave-slot\n", name, N, (int)MFMA, CHAINS, wps,
+           ms * 1e-3 * 2.4e9 / ITER);
+  }
+}
+
+int main() {
+  float* out;
+  hipMalloc((void**)&out, 512 * 256 * 4);
+  run<0, 5, 1, true>("mfma only", out);
+  run<0, 5, 2, true>("mfma only", out);
+  run<4, 0, 1, true>("v_fma_f32", out);
+  run<8, 0, 1, true>("v_fma_f32", out);
+  run<12, 0, 1, true>("v_fma_f32", out);
+  run<16, 0, 1, true>("v_fma_f32", out);
+  run<8, 0, 2, true>("v_fma_f32", out);
+  run<16, 0, 1, false>("v_fma_f32", out);
+  run<16, 1, 1, false>("v_pk_fma_f32", out);
+  run<8, 1, 1, true>("v_pk_fma_f32", out);
+  run<16, 2, 1, false>("v_cvt_pk_bf16_f32", out);
+  run<8, 2, 1, true>("v_cvt_pk_bf16_f32", out);
+  run<16, 3, 1, false>("v_exp_f32", out);
+  run<4, 3, 1, true>("v_exp_f32", out);
+  run<8, 4, 1, false>("v_cmp+nop+cndmask", out);
+  hipDeviceSynchronize();
+  printf("done\n");
+  return 0;
+}

@@ -16,6 +16,8 @@
 // TRANSPOSED, two keys per ds_write_b32, with the key order inside a row permuted so that the 8 keys one lane contracts
 // in k-step s (the C-layout rows 16 s + 4 hi + {0..3, 8..11} of S^T, which are the P registers 8 s .. 8 s + 7) are one
 // 16-byte run: P never moves between lanes, exactly as in the fp32 kernel.
+#include <type_traits>
+
 #include "vx_common.h"
 
 namespace vx {
@@ -23,6 +25,9 @@ namespace vx {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -40,6 +45,64 @@ __device__ __forceinline__ float exp_bf(float x) {           // see attn_full.hi
   const float pl = fmaf(x, L2E, -ph) + x * L2E_LO;
   const float e = __builtin_amdgcn_exp2f(ph);
   return fmaf(e, pl * LN2, e);
+}
+
+// compile-time loop: the slot bodies are instantiated per index (a 24-trip `#pragma unroll` over a body holding every
+// slot's code exceeds LLVM's full-unroll budget and falls back to a runtime loop with indexed registers)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// Keep a value where the source computes it: an empty volatile asm that "modifies" it is ordered against the other
+// pins and the sched_barriers, so neither instruction selection nor the IR sink pass can move the producing arithmetic.
+__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(unsigned& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin16(f32x16& x) { asm volatile("" : "+v"(x)); }
+
+// (x, y) -> three packed bf16 pairs (x in the low half): w1 + w2 + w3 == (x, y) to 2^-27 relative; pinned.
+// v_cvt_pk_bf16_f32 (RNE) once per term, the bf16 -> f32 widenings are a shift and a mask of the packed word.
+__device__ __forceinline__ unsigned cvt_pk_bf16(f32x2 v) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ f32x2 widen_pk_bf16(unsigned w) {
+  return f32x2{__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+}
+__device__ __forceinline__ void pin2(f32x2& x) { asm volatile("" : "+v"(x)); }
+// the same in two halves (terms 1-2 and the second residual | term 3), so a split can straddle two MFMA slots
+__device__ __forceinline__ void split3_pair_a(float x, float y, unsigned& w1, unsigned& w2, f32x2& res) {
+  const f32x2 v = {x, y};
+  w1 = cvt_pk_bf16(v);
+  const f32x2 r1 = v - widen_pk_bf16(w1);
+  w2 = cvt_pk_bf16(r1);
+  res = r1 - widen_pk_bf16(w2);
+  pin(w1); pin(w2); pin2(res);
+}
+__device__ __forceinline__ void split3_pair_b(f32x2 res, unsigned& w3) {
+  w3 = cvt_pk_bf16(res);
+  pin(w3);
+}
+__device__ __forceinline__ void split3_pair(float x, float y, unsigned& w1, unsigned& w2, unsigned& w3) {
+  const f32x2 v = {x, y};
+  w1 = cvt_pk_bf16(v);
+  const f32x2 r1 = v - widen_pk_bf16(w1);                      // exact
+  w2 = cvt_pk_bf16(r1);
+  w3 = cvt_pk_bf16(r1 - widen_pk_bf16(w2));                    // exact difference, rounded once
+  pin(w1); pin(w2); pin(w3);
+}
+
+// exp_bf on a pair (packed f32 arithmetic around the two v_exp_f32)
+__device__ __forceinline__ f32x2 exp_bf2(f32x2 x) {
+  const float L2E = 1.44269504088896341f, L2E_LO = 1.925963033500649e-08f, LN2 = 0.6931471805599453f;
+  const f32x2 ph = x * L2E;
+  f32x2 pl = {fmaf(x[0], L2E, -ph[0]), fmaf(x[1], L2E, -ph[1])};
+  pl = pl + x * L2E_LO;
+  const f32x2 e = {__builtin_amdgcn_exp2f(ph[0]), __builtin_amdgcn_exp2f(ph[1])};
+  const f32x2 q = pl * LN2;
+  return f32x2{fmaf(e[0], q[0], e[0]), fmaf(e[1], q[1], e[1])};
 }
 
 __device__ __forceinline__ void split3(float v, __bf16& a1, __bf16& a2, __bf16& a3) {
@@ -119,6 +182,8 @@ __global__ __launch_bounds__(256, 2) void attn_full_x3_kernel(const float* __res
   // position of key 2 kp inside a V^T row: keys of (s, hi) = 16 s + 4 hi + {0,1,2,3,8,9,10,11} are positions 8 (2 s + hi) + j
   const int vpos = ((kp2 >> 4) * 2 + ((kp2 >> 2) & 1)) * 8 + (kp2 & 3) + 4 * ((kp2 >> 3) & 1);
   f32x4 rk[2], rv[2];
+  unsigned kw[2][3][2];                                        // split K of the staged tile: [float4 i][plane][pair]
+  unsigned vw[4][3];                                           // split V: [dim e][plane] = (key 2 kp, key 2 kp + 1)
   auto issue = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -130,41 +195,40 @@ __global__ __launch_bounds__(256, 2) void attn_full_x3_kernel(const float* __res
       rv[i] = *reinterpret_cast<const f32x4*>(vbase + kv * (long)(3 * D_MODEL) + c4);
     }
   };
-  auto stage_write = [&](int buf) {
+  // split slices, each pinned where it is written (see pin3)
+  auto split_k = [&](int i, int pr) { split3_pair(rk[i][2 * pr], rk[i][2 * pr + 1], kw[i][0][pr], kw[i][1][pr], kw[i][2][pr]); };
+  auto split_v = [&](int e) { split3_pair(rv[0][e], rv[1][e], vw[e][0], vw[e][1], vw[e][2]); };
+  auto split_all = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { split_k(i, 0); split_k(i, 1); }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_v(e);
+  };
+  auto stage_write = [&](int buf) {                            // LDS stores only: the split happened under the MFMAs
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int key = (tid + 256 * i) >> 4;
-      bf16x4 p1, p2, p3;
+      const int off = ((tid + 256 * i) >> 4) * KP_LD + c4 * 2;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        __bf16 a1, a2, a3;
-        split3(rk[i][e], a1, a2, a3);
-        p1[e] = a1; p2[e] = a2; p3[e] = a3;
-      }
-      const int off = key * KP_LD + c4 * 2;
-      *reinterpret_cast<bf16x4*>(&Kp[buf][0][off]) = p1;
-      *reinterpret_cast<bf16x4*>(&Kp[buf][1][off]) = p2;
-      *reinterpret_cast<bf16x4*>(&Kp[buf][2][off]) = p3;
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(&Kp[buf][p][off]) = u32x2{kw[i][p][0], kw[i][p][1]};
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      bf16x2 p1, p2, p3;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        __bf16 a1, a2, a3;
-        split3(rv[i][e], a1, a2, a3);
-        p1[i] = a1; p2[i] = a2; p3[i] = a3;
-      }
       const int off = vt_row(c4 + e) + vpos * 2;
-      *reinterpret_cast<bf16x2*>(&Vt[buf][0][off]) = p1;
-      *reinterpret_cast<bf16x2*>(&Vt[buf][1][off]) = p2;
-      *reinterpret_cast<bf16x2*>(&Vt[buf][2][off]) = p3;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(&Vt[buf][p][off]) = vw[e][p];
     }
   };
   auto kfrag = [&](int buf, int s, bf16x8 (&kf)[3]) {
 #pragma unroll
     for (int p = 0; p < 3; ++p)
       kf[p] = *reinterpret_cast<const bf16x8*>(&Kp[buf][p][l31 * KP_LD + (2 * s + hi) * 16]);
+  };
+  auto vfrag = [&](int buf, int s, bf16x8 (&v0)[3], bf16x8 (&v1)[3]) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      v0[p] = *reinterpret_cast<const bf16x8*>(&Vt[buf][p][vt_row(l31) + (2 * s + hi) * 16]);
+      v1[p] = *reinterpret_cast<const bf16x8*>(&Vt[buf][p][vt_row(l31 + 32) + (2 * s + hi) * 16]);
+    }
   };
   auto qk = [&](int buf) {
     f32x16 s16;
@@ -179,112 +243,156 @@ __global__ __launch_bounds__(256, 2) void attn_full_x3_kernel(const float* __res
     return s16;
   };
 
-  // same software pipeline as attn_full.hip: QK^T of tile t+1 is issued before the softmax of tile t
+  // Visibility as ONE per-lane key limit: key kj is visible to query qi iff kj < lim, lim = min(len, qi >= S ? qi + 1 : S)
+  // (text queries see the text, audio queries everything up to themselves; S = INT_MAX without a mask).
+  const int lim = min(len, qi >= S ? qi + 1 : S);
+
+  // Software pipeline as in attn_full.hip (QK^T of tile t+1 is issued before the softmax of tile t), plus: tile t+2
+  // travels global -> registers during iteration t, is SPLIT under the PV MFMAs of iteration t and stored to LDS at its
+  // end, so the serial section between the two barriers is 18 LDS stores.
+  //
+  // Issue order inside a wave is what makes the matrix pipe and the VALU overlap: the wave issues in order, an MFMA
+  // occupies the pipe for 32 cycles, and an MFMA waiting for the pipe blocks everything behind it.  Each phase is
+  // therefore 24 slots of [1 MFMA | <= ~10 VALU/LDS instructions]; LDS fragments are requested one k-step (6 slots)
+  // before their MFMAs.  The slices are pure arithmetic, which LLVM places wherever it likes (it sank them below the
+  // MFMAs, or into a later conditional block): every slice ends in pin()s -- empty volatile asm that reads and writes
+  // the values just produced -- and every slot in sched_barrier(0).
   const int ntiles = (kv_end + KT - 1) / KT;
   issue(0);
+  split_all();
   stage_write(0);
   __syncthreads();
-  if (1 < ntiles) issue(KT);
+  if (1 < ntiles) { issue(KT); split_all(); }
   f32x16 s_cur = qk(0);
   if (1 < ntiles) stage_write(1);
   __syncthreads();
   if (2 < ntiles) issue(2 * KT);
+  bf16x8 kfa[3], kfb[3];                                       // K fragments of even / odd k-steps
+  kfrag(1, 0, kfa);                                            // (tile 1; a stale buffer if there is none: discarded)
+  // wave-uniform "every key of tile t is visible to every query of this wave" test: (t + 1) * KT <= min over lanes of lim
+  int lim_min = lim;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) lim_min = min(lim_min, __shfl_xor(lim_min, m, 64));
+  lim_min = __builtin_amdgcn_readfirstlane(lim_min);
 
-  for (int t = 0; t < ntiles; ++t) {
-    const int k0 = t * KT, cur = t & 1, nxt = cur ^ 1;
-    // ---- phase 1: S^T of tile t+1 (24 MFMAs) with the softmax of tile t threaded through it: 12 steps of
-    // [2 MFMAs | one slice of the softmax], fenced by sched_barrier(0).
-    f32x16 sA;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sA[r] = 0.f;
-    bf16x8 kf[3];
-    float m_new = m_run, alpha = 1.f, psum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      const int s = i / 3, j = i - 3 * s;
-      if (j == 0) kfrag(nxt, s, kf);
-      if (V == 2) {
-        sA[0] += (float)kf[j][0] * (float)qp[s][j][0];
-      } else if (j == 0) {
-        sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2], qp[s][0], sA, 0, 0, 0);
-        sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qp[s][2], sA, 0, 0, 0);
-      } else if (j == 1) {
-        sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qp[s][1], sA, 0, 0, 0);
-        sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qp[s][0], sA, 0, 0, 0);
+  // One tile iteration.  The loop is unrolled by two so that the score registers alternate roles (s_cur: scores of tile
+  // t, consumed; sA: scores of tile t+1, produced) without a 16-register copy, and the LDS buffer index is a constant.
+  auto tile = [&](auto curc, int t, f32x16& s_cur, f32x16& sA) {
+    constexpr int cur = decltype(curc)::value, nxt = cur ^ 1;
+    const int lim_t = lim - t * KT - 4 * hi;                   // register r holds key offset (r&3) + 8 (r>>2) of this lane
+    const bool need_mask = (t + 1) * KT > lim_min;             // scalar
+    bf16x8 v0[3], v1[3], w0[3], w1[3];                         // V^T fragments of k-step 0 / 1, both halves of d
+    unsigned pw[2][3][4];                                      // P planes of k-step s as packed pairs: [s][plane][pair]
+    f32x2 res;                                                 // second residual of the split in flight
+    float m_new = m_run, alpha = 1.f, psum = 0.f, m_tile = MASKED;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // a split is cut in two halves (terms 1-2 | term 3) that go behind consecutive MFMAs
+    auto split_p_a = [&](int s, int pr) { split3_pair_a(s_cur[8 * s + 2 * pr], s_cur[8 * s + 2 * pr + 1], pw[s][0][pr], pw[s][1][pr], res); };
+    auto split_p_b = [&](int s, int pr) { split3_pair_b(res, pw[s][2][pr]); };
+    // ---- phase 1: S^T of tile t+1 (24 MFMAs, one chain) with the softmax of tile t threaded through it
+    //   slots 0-3 mask | 4-5 running max, alpha | 6,8,..,20 exp pairs | 7,9,11,13 rescale O | 15-22 split P (k-step 0)
+    static_for<0, 24>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int s = i / 6, j = i - 6 * s;
+      constexpr int pa = j == 0 ? 2 : (j == 2 || j == 3) ? 1 : 0;     // plane of K
+      constexpr int pb = j == 1 ? 2 : (j == 2 || j == 4) ? 1 : 0;     // plane of Q
+      if constexpr (j == 0 && s < 3) kfrag(nxt, s + 1, (s & 1) ? kfa : kfb);   // next k-step's fragments
+      if constexpr (i == 18) vfrag(cur, 0, v0, v1);
+      if constexpr (V == 2) {
+        sA[0] = (i ? sA[0] : 0.f) + (float)((s & 1) ? kfb : kfa)[pa][0] * (float)qp[s][pb][0];
       } else {
-        sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qp[s][1], sA, 0, 0, 0);
-        sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qp[s][0], sA, 0, 0, 0);
+        sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16((s & 1) ? kfb[pa] : kfa[pa], qp[s][pb], i ? sA : zero, 0, 0, 0);
       }
-      if (V == 3) {
-        // probe: no softmax work at all
-      } else if (i < 4) {                                      // steps 0-3: visibility mask, 4 keys per step
+      if constexpr (V == 3) {
+        if constexpr (i == 21) {
 #pragma unroll
-        for (int r = 4 * i; r < 4 * i + 4; ++r) {
-          const int kj = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          const bool vis = (kj < len) & ((kj < S) | ((qi >= S) & (kj <= qi)));
-          s_cur[r] = vis ? s_cur[r] : MASKED;
+          for (int pr = 0; pr < 4; ++pr) { split_p_a(0, pr); split_p_b(0, pr); }
         }
-      } else if (i == 4) {                                     // step 4: running max (other 16 keys live in lane ^ 32)
-        float m_tile = MASKED;
+      } else if constexpr (i < 4) {                            // visibility, 4 keys per slot (interior tiles skip it)
+        if (need_mask) {
+          float mv[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mv[r] = ((r + 8 * i) < lim_t) ? s_cur[4 * i + r] : MASKED;   // key offset of reg 4i+r
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { pin(mv[r]); s_cur[4 * i + r] = mv[r]; }
+        }
+      } else if constexpr (i == 4) {                           // tile max of this lane's 16 keys
 #pragma unroll
         for (int r = 0; r < 16; ++r) m_tile = fmaxf(m_tile, s_cur[r]);
+        pin(m_tile);
+      } else if constexpr (i == 5) {                           // the other 16 keys live in lane ^ 32
         const unsigned um = __builtin_bit_cast(unsigned, m_tile);
         const auto sw = __builtin_amdgcn_permlane32_swap(um, um, false, false);
         m_tile = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
         m_new = fmaxf(m_run, m_tile);                          // finite: key 0 is visible to every query
         alpha = exp_bf(m_run - m_new);
-      } else if (i < 11) {                                     // steps 5-10: 3,3,3,3,2,2 exps
-        const int r0 = i < 9 ? 3 * (i - 5) : 12 + 2 * (i - 9), r1 = i < 9 ? r0 + 3 : r0 + 2;
+        pin(m_new);
+        pin(alpha);
+      } else if constexpr (i < 22 && !(i & 1)) {               // slots 6, 8, .., 20: one pair of exps
+        constexpr int r = i - 6;
+        f32x2 ev = exp_bf2(f32x2{s_cur[r] - m_new, s_cur[r + 1] - m_new});
+        pin2(ev);
+        s_cur[r] = ev[0];
+        s_cur[r + 1] = ev[1];
+        psum += ev[0] + ev[1];
+        pin(psum);
+        if constexpr (i >= 16) split_p_b(0, (i - 16) >> 1);    // second half of the split begun in slot i - 1
+      } else if constexpr (i < 14) {                           // slots 7, 9, 11, 13: rescale a quarter of O
+        constexpr int q = (i - 7) >> 1;
 #pragma unroll
-        for (int r = r0; r < r1; ++r) { s_cur[r] = exp_bf(s_cur[r] - m_new); psum += s_cur[r]; }
-      } else {                                                 // step 11: running sum, rescale O
+        for (int r = 0; r < 8; r += 2) {
+          f32x2 v = f32x2{o[q >> 1][8 * (q & 1) + r], o[q >> 1][8 * (q & 1) + r + 1]} * alpha;
+          pin2(v);
+          o[q >> 1][8 * (q & 1) + r] = v[0];
+          o[q >> 1][8 * (q & 1) + r + 1] = v[1];
+        }
+      } else if constexpr (i < 22) {                           // slots 15, 17, 19, 21: first half of a P split (k-step 0)
+        split_p_a(0, (i - 15) >> 1);
+      } else if constexpr (i == 22) {
+        split_p_b(0, 3);
         l_run = l_run * alpha + psum;
         m_run = m_new;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
       }
       __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- phase 2: O^T += V^T . P^T: P split in registers (B operand), V^T planes from LDS, 24 MFMAs in two chains
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 pp[3];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        __bf16 a1, a2, a3;
-        split3(s_cur[8 * s + e], a1, a2, a3);
-        pp[0][e] = a1; pp[1][e] = a2; pp[2][e] = a3;
-      }
-      bf16x8 v0[3], v1[3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        v0[p] = *reinterpret_cast<const bf16x8*>(&Vt[cur][p][vt_row(l31) + (2 * s + hi) * 16]);
-        v1[p] = *reinterpret_cast<const bf16x8*>(&Vt[cur][p][vt_row(l31 + 32) + (2 * s + hi) * 16]);
-      }
-      if (V == 2) {
-        o[0][0] += (float)v0[0][0] * (float)pp[0][0] + (float)v0[1][1] * (float)pp[1][1] + (float)v0[2][2] * (float)pp[2][2];
-        o[1][0] += (float)v1[0][0] * (float)pp[0][0] + (float)v1[1][1] * (float)pp[1][1] + (float)v1[2][2] * (float)pp[2][2];
+    });
+    // ---- phase 2: O^T += V^T . P^T, 24 MFMAs in two chains (o[0], o[1]); a split pair per two slots:
+    //   slots 0-7 P (k-step 1) | 8-15 the staged K tile | 16-23 the staged V tile (registers hold tile t+2; past the
+    //   last tile they are stale and the result is not stored)
+    static_for<0, 24>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int s = i / 12, j = (i - 12 * s) >> 1, half = i & 1;
+      constexpr int pa = j == 0 ? 2 : (j == 2 || j == 3) ? 1 : 0;     // plane of V^T
+      constexpr int pb = j == 1 ? 2 : (j == 2 || j == 4) ? 1 : 0;     // plane of P
+      if constexpr (i == 1) vfrag(cur, 1, w0, w1);
+      const bf16x8 pf = __builtin_bit_cast(bf16x8, u32x4{pw[s][pb][0], pw[s][pb][1], pw[s][pb][2], pw[s][pb][3]});
+      const bf16x8 vf = s ? (half ? w1[pa] : w0[pa]) : (half ? v1[pa] : v0[pa]);
+      if constexpr (V == 2) o[half][0] += (float)vf[0] * (float)pf[0];
+      else o[half] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[half], 0, 0, 0);
+      constexpr int q = i >> 1;
+      if constexpr (q < 4) {
+        if constexpr (!half) split_p_a(1, q); else split_p_b(1, q);
+      } else if constexpr (q < 8) {
+        constexpr int ki = (q - 4) >> 1, pr = (q - 4) & 1;
+        if constexpr (!half) split3_pair_a(rk[ki][2 * pr], rk[ki][2 * pr + 1], kw[ki][0][pr], kw[ki][1][pr], res);
+        else split3_pair_b(res, kw[ki][2][pr]);
       } else {
-        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0[2], pp[0], o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1[2], pp[0], o[1], 0, 0, 0);
-        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0[0], pp[2], o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1[0], pp[2], o[1], 0, 0, 0);
-        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0[1], pp[1], o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1[1], pp[1], o[1], 0, 0, 0);
-        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0[1], pp[0], o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1[1], pp[0], o[1], 0, 0, 0);
-        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0[0], pp[1], o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1[0], pp[1], o[1], 0, 0, 0);
-        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0[0], pp[0], o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1[0], pp[0], o[1], 0, 0, 0);
+        constexpr int e = q - 8;
+        if constexpr (!half) split3_pair_a(rv[0][e], rv[1][e], vw[e][0], vw[e][1], res);
+        else split3_pair_b(res, vw[e][2]);
       }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s_cur[r] = sA[r];
+      __builtin_amdgcn_sched_barrier(0);
+    });
     __syncthreads();                                           // everyone is done reading buffer `cur`
-    if (V != 1 && t + 2 < ntiles) stage_write(cur);            // registers hold tile t+2
+    if (V != 1 && t + 2 < ntiles) stage_write(cur);            // tile t+2, already split
     __syncthreads();
+    kfrag(cur, 0, kfa);                                        // first K fragments of the next iteration's tile (t+2)
     if (V != 1 && t + 3 < ntiles) issue((t + 3) * KT);
+  };
+
+  f32x16 s_odd;
+  for (int t = 0; t < ntiles; t += 2) {
+    tile(std::integral_constant<int, 0>{}, t, s_cur, s_odd);
+    if (t + 1 < ntiles) tile(std::integral_constant<int, 1>{}, t + 1, s_odd, s_cur);
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
