@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256, 2) void attn_full_x3_kernel(const float* __res
                                                              const int* __restrict__ seq_off,
                                                              const int* __restrict__ seq_len,
                                                              const int* __restrict__ prefix_len, int nqb) {
-  __shared__ __attribute__((aligned(16))) unsigned char Kp[2][3][KP_SZ];
-  __shared__ __attribute__((aligned(16))) unsigned char Vt[2][3][VT_SZ];
+  __shared__ __attribute__((aligned(16))) unsigned char Kp[3][3][KP_SZ];   // [buffer][plane]
+  __shared__ __attribute__((aligned(16))) unsigned char Vt[3][3][VT_SZ];
 
   // XCD-aware work order: a unit's query blocks share one XCD's L2 (see attn_full.hip)
   const int id = blockIdx.x, per8 = 8 * nqb;
@@ -204,19 +204,22 @@ __global__ __launch_bounds__(256, 2) void attn_full_x3_kernel(const float* __res
 #pragma unroll
     for (int e = 0; e < 4; ++e) split_v(e);
   };
-  auto stage_write = [&](int buf) {                            // LDS stores only: the split happened under the MFMAs
+  // LDS stores of the split tile (the split itself happens under the MFMAs)
+  auto write_k = [&](int buf, int i) {
+    const int off = ((tid + 256 * i) >> 4) * KP_LD + c4 * 2;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int off = ((tid + 256 * i) >> 4) * KP_LD + c4 * 2;
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(&Kp[buf][p][off]) = u32x2{kw[i][p][0], kw[i][p][1]};
+  };
+  auto write_v = [&](int buf, int e) {
+    const int off = vt_row(c4 + e) + vpos * 2;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x2*>(&Kp[buf][p][off]) = u32x2{kw[i][p][0], kw[i][p][1]};
-    }
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(&Vt[buf][p][off]) = vw[e][p];
+  };
+  auto stage_write = [&](int buf) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int off = vt_row(c4 + e) + vpos * 2;
+    for (int i = 0; i < 2; ++i) write_k(buf, i);
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<unsigned*>(&Vt[buf][p][off]) = vw[e][p];
-    }
+    for (int e = 0; e < 4; ++e) write_v(buf, e);
   };
   auto kfrag = [&](int buf, int s, bf16x8 (&kf)[3]) {
 #pragma unroll
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void attn_full_x3_kernel(const float* __res
 
   // Software pipeline as in attn_full.hip (QK^T of tile t+1 is issued before the softmax of tile t), plus: tile t+2
   // travels global -> registers during iteration t, is SPLIT under the PV MFMAs of iteration t and stored to LDS at its
-  // end, so the serial section between the two barriers is 18 LDS stores.
+  // end; with three LDS buffers the stores go out under those MFMAs too and one barrier per tile is enough.
   //
   // Issue order inside a wave is what makes the matrix pipe and the VALU overlap: the wave issues in order, an MFMA
   // occupies the pipe for 32 cycles, and an MFMA waiting for the pipe blocks everything behind it.  Each phase is
@@ -261,12 +264,10 @@ __global__ __launch_bounds__(256, 2) void attn_full_x3_kernel(const float* __res
   issue(0);
   split_all();
   stage_write(0);
-  __syncthreads();
-  if (1 < ntiles) { issue(KT); split_all(); }
-  f32x16 s_cur = qk(0);
-  if (1 < ntiles) stage_write(1);
+  if (1 < ntiles) { issue(KT); split_all(); stage_write(1); }
   __syncthreads();
   if (2 < ntiles) issue(2 * KT);
+  f32x16 s_cur = qk(0);
   bf16x8 kfa[3], kfb[3];                                       // K fragments of even / odd k-steps
   kfrag(1, 0, kfa);                                            // (tile 1; a stale buffer if there is none: discarded)
   // wave-uniform "every key of tile t is visible to every query of this wave" test: (t + 1) * KT <= min over lanes of lim
@@ -277,8 +278,7 @@ __global__ __launch_bounds__(256, 2) void attn_full_x3_kernel(const float* __res
 
   // One tile iteration.  The loop is unrolled by two so that the score registers alternate roles (s_cur: scores of tile
   // t, consumed; sA: scores of tile t+1, produced) without a 16-register copy, and the LDS buffer index is a constant.
-  auto tile = [&](auto curc, int t, f32x16& s_cur, f32x16& sA) {
-    constexpr int cur = decltype(curc)::value, nxt = cur ^ 1;
+  auto tile = [&](int t, int cur, int nxt, int wr, f32x16& s_cur, f32x16& sA) {
     const int lim_t = lim - t * KT - 4 * hi;                   // register r holds key offset (r&3) + 8 (r>>2) of this lane
     const bool need_mask = (t + 1) * KT > lim_min;             // scalar
     bf16x8 v0[3], v1[3], w0[3], w1[3];                         // V^T fragments of k-step 0 / 1, both halves of d
@@ -375,24 +375,29 @@ __global__ __launch_bounds__(256, 2) void attn_full_x3_kernel(const float* __res
         constexpr int ki = (q - 4) >> 1, pr = (q - 4) & 1;
         if constexpr (!half) split3_pair_a(rk[ki][2 * pr], rk[ki][2 * pr + 1], kw[ki][0][pr], kw[ki][1][pr], res);
         else split3_pair_b(res, kw[ki][2][pr]);
+        if constexpr (V != 1 && half && pr == 1) write_k(wr, ki);
       } else {
         constexpr int e = q - 8;
         if constexpr (!half) split3_pair_a(rv[0][e], rv[1][e], vw[e][0], vw[e][1], res);
         else split3_pair_b(res, vw[e][2]);
+        if constexpr (V != 1 && half) write_v(wr, e);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
-    __syncthreads();                                           // everyone is done reading buffer `cur`
-    if (V != 1 && t + 2 < ntiles) stage_write(cur);            // tile t+2, already split
+    // One barrier per tile: buffer `wr` (tile t+2; past the last tile a stale copy nobody reads) was last read in
+    // iteration t-1, is written above, and is first read below / in iteration t+1.
     __syncthreads();
-    kfrag(cur, 0, kfa);                                        // first K fragments of the next iteration's tile (t+2)
+    kfrag(wr, 0, kfa);                                         // first K fragments of the next iteration's tile (t+2)
     if (V != 1 && t + 3 < ntiles) issue((t + 3) * KT);
   };
 
   f32x16 s_odd;
+  int b0 = 0, b1 = 1, b2 = 2;                                  // buffers of tiles t, t+1, t+2
   for (int t = 0; t < ntiles; t += 2) {
-    tile(std::integral_constant<int, 0>{}, t, s_cur, s_odd);
-    if (t + 1 < ntiles) tile(std::integral_constant<int, 1>{}, t + 1, s_odd, s_cur);
+    tile(t, b0, b1, b2, s_cur, s_odd);
+    if (t + 1 < ntiles) tile(t + 1, b1, b2, b0, s_odd, s_cur);
+    const int r0 = b0;                                         // advance by two tiles
+    b0 = b2; b2 = b1; b1 = r0;
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
