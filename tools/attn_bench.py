@@ -14,7 +14,10 @@ for B, L in ((32, 988), (8, 77)):
     for causal in (False, True):
         for base, kname in ((0, "f32"), (10, "x3 ")):
             row = [f"B={B} L={L} causal={int(causal)} {kname}"]
-            for v, name in ((0, "full"), (1, "no-staging"), (2, "no-mfma"), (3, "no-softmax")):
+            probes = ((0, "full"), (1, "no-staging"), (2, "no-mfma"), (3, "no-softmax"))
+            if base == 10:
+                probes += ((4, "no-lds-store"), (5, "no-global-load"))
+            for v, name in probes:
                 us, md = eng.bench_attn(B, L, causal, base + v, 5)
                 row.append(f"{name}: {us:8.1f} us ({flops / us / 1e6:6.1f} TF)" + (f" diff {md:.3g}" if v == 0 else ""))
             print("  |  ".join(row), flush=True)

@@ -124,7 +124,7 @@ __device__ __forceinline__ void split3(float v, __bf16& a1, __bf16& a2, __bf16& 
 }  // namespace
 
 // V = 0 product kernel.  Timing probes (tools/attn_bench.py, results meaningless): V = 1 no K/V staging after the first
-// two tiles; V = 2 no MFMAs; V = 3 no softmax arithmetic.
+// two tiles (V = 4: only the LDS stores dropped, V = 5: only the global loads); V = 2 no MFMAs; V = 3 no softmax arithmetic.
 template <int V>
 __global__ __launch_bounds__(256, 2) void attn_full_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                              const int* __restrict__ seq_off,
@@ -375,12 +375,12 @@ __global__ __launch_bounds__(256, 2) void attn_full_x3_kernel(const float* __res
         constexpr int ki = (q - 4) >> 1, pr = (q - 4) & 1;
         if constexpr (!half) split3_pair_a(rk[ki][2 * pr], rk[ki][2 * pr + 1], kw[ki][0][pr], kw[ki][1][pr], res);
         else split3_pair_b(res, kw[ki][2][pr]);
-        if constexpr (V != 1 && half && pr == 1) write_k(wr, ki);
+        if constexpr (V != 1 && V != 4 && half && pr == 1) write_k(wr, ki);
       } else {
         constexpr int e = q - 8;
         if constexpr (!half) split3_pair_a(rv[0][e], rv[1][e], vw[e][0], vw[e][1], res);
         else split3_pair_b(res, vw[e][2]);
-        if constexpr (V != 1 && half) write_v(wr, e);
+        if constexpr (V != 1 && V != 4 && half) write_v(wr, e);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void attn_full_x3_kernel(const float* __res
     // iteration t-1, is written above, and is first read below / in iteration t+1.
     __syncthreads();
     kfrag(wr, 0, kfa);                                         // first K fragments of the next iteration's tile (t+2)
-    if (V != 1 && t + 3 < ntiles) issue((t + 3) * KT);
+    if (V != 1 && V != 5 && t + 3 < ntiles) issue((t + 3) * KT);
   };
 
   f32x16 s_odd;
@@ -424,6 +424,8 @@ void launch_attn_full_x3(const float* qkv, float* out, const int* seq_off, const
   if (variant == 1) hipLaunchKernelGGL(attn_full_x3_kernel<1>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
   else if (variant == 2) hipLaunchKernelGGL(attn_full_x3_kernel<2>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
   else if (variant == 3) hipLaunchKernelGGL(attn_full_x3_kernel<3>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
+  else if (variant == 4) hipLaunchKernelGGL(attn_full_x3_kernel<4>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
+  else if (variant == 5) hipLaunchKernelGGL(attn_full_x3_kernel<5>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
   else hipLaunchKernelGGL(attn_full_x3_kernel<0>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
 }
 
