@@ -70,6 +70,7 @@ struct vx_ctx {
 
   // bf16x3 GEMM path (default) for the transformer projections of prefill / NAR; VX_GEMM_F32=1 keeps the fp32 MFMA
   bool x3 = true;
+  bool gemm_dma = true;                       // async-LDS bf16x3 GEMM (gemm_bf16x3_dma.hip); VX_GEMM_DMA=0 keeps the register-staged one
   bool attn_x3 = true;                        // bf16x3 attention (attn_full_x3.hip); VX_ATTN_F32=1 keeps the fp32 MFMA kernel
   unsigned short* fa3 = nullptr;   // activation planes [3][M][K<=4096]
   unsigned short* pred_w3[N_Q - 1] = {};
@@ -242,7 +243,8 @@ void proj(vx_ctx* c, const float* A, int lda, const float* Wf, const unsigned sh
   g.colscale = nullptr; g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.act = act;
   ProfScope ps(c, 2);
   if (c->prof_on) c->prof[2].bytes += 2.0 * (double)M * N * K;
-  launch_gemm_bf16x3(g, c->stream);
+  if (c->gemm_dma && M >= 1024) launch_gemm_bf16x3_dma(g, c->stream);   // 256-row tiles: not for short row sets
+  else launch_gemm_bf16x3(g, c->stream);
 }
 
 // one pre-norm block on packed rows (modules/transformer.py:296-302 / :337-347) -- shared by AR prefill and NAR
@@ -787,6 +789,7 @@ int vx_finalize_weights(vx_ctx* c) {
   // ---- bf16 triple planes of every transformer projection used on the full-sequence paths ----
   if (const char* ev = getenv("VX_GEMM_F32")) c->x3 = !(ev[0] == '1');
   if (const char* ev = getenv("VX_ATTN_F32")) c->attn_x3 = !(ev[0] == '1');
+  if (const char* ev = getenv("VX_GEMM_DMA")) c->gemm_dma = !(ev[0] == '0');
   if (c->x3) {
     auto split_w = [&](const float* Wt, int N, int K, unsigned short** out) -> int {
       if (int e2 = dev_alloc(c, out, (size_t)3 * N * K, false)) return e2;
@@ -1436,7 +1439,7 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
 }
 
 // Stand-alone GEMM micro-benchmark on scratch buffers (kernel development aid; never on the product path):
-// kernel 0 = gemm_f32, 1 = gemm_bf16x3.  Reports the average launch time and the max abs
+// kernel 0 = gemm_f32, 1 = gemm_bf16x3, 2 = gemm_bf16x3_dma.  Reports the average launch time and the max abs
 // difference of the first 256 output rows against the fp32-MFMA kernel.
 int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, int32_t reps, double* avg_us,
                   double* max_abs_diff) {
@@ -1475,6 +1478,7 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
   auto run = [&]() {
     if (kernel == 0) launch_gemm_f32(g1, c->stream);
     else if (kernel == 1) launch_gemm_bf16x3(gx, c->stream);
+    else if (kernel == 2) launch_gemm_bf16x3_dma(gx, c->stream);
     else launch_gemm_bf16x3_probe(gx, kernel - 10, c->stream);      // 11 / 12 / 13: timing probes
   };
   run();
