@@ -11,9 +11,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int ITER = 4000;
 
-// OP: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_cvt_pk_bf16_f32, 3 v_exp_f32, 4 v_cndmask (cmp+cndmask pair), 5 none
+// OP: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_cvt_pk_bf16_f32, 3 v_exp_f32, 4 v_cndmask (cmp+cndmask pair), 5 none,
+//     6 ds_read_b128 (conflict-free, results unused but waited for every iteration), 7 ds_read_b128 feeding the MFMA's A operand
 template <int N, int OP, int CHAINS, bool MFMA>
 __global__ __launch_bounds__(256) void k(float* out, int iters) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[16384];
+  for (int i = threadIdx.x; i < 4096; i += 256) reinterpret_cast<float*>(lds)[i] = 0.001f * i;
+  __syncthreads();
+  const unsigned laddr = (unsigned)(size_t)lds + (threadIdx.x & 63) * 16;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 ld[4];
   bf16x8 a, b;
   for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(threadIdx.x * 0.001f + e); b[e] = (__bf16)(e * 0.5f); }
   f32x16 c0 = {0}, c1 = {0};
@@ -34,13 +41,18 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
       if (OP == 1) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(pv[n & 7]));
       if (OP == 2) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[n & 15]) : "v"(v[n & 15]), "v"(v[(n + 1) & 15]));
       if (OP == 3) asm volatile("v_exp_f32 %0, %0" : "+v"(v[n & 15]));
+      if (OP == 6) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld[n & 3]) : "v"(laddr), "n"((n & 7) * 1024));
+      if (OP == 7) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a) : "v"(laddr), "n"((n & 7) * 1024));
       if (OP == 4) asm volatile("v_cmp_lt_i32 vcc, %1, %2\n\ts_nop 1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(w[n & 15]) : "v"(w[(n + 1) & 15]), "v"(w[(n + 2) & 15]) : "vcc");
     }
+    if (OP == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ld[0]), "+v"(ld[1]), "+v"(ld[2]), "+v"(ld[3]));
+    if (OP == 7) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a));
     __builtin_amdgcn_sched_barrier(0);
   }
   float acc = 0;
   for (int e = 0; e < 16; ++e) acc += c0[e] + c1[e] + v[e] + (float)w[e];
   for (int e = 0; e < 8; ++e) acc += pv[e][0] + pv[e][1];
+  for (int e = 0; e < 4; ++e) acc += ld[e][0] + (float)a[e];
   out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
@@ -65,21 +77,15 @@ void run(const char* name, float* out) {
 int main() {
   float* out;
   hipMalloc((void**)&out, 512 * 256 * 4);
+  run<0, 5, 1, true>("warmup", out);
   run<0, 5, 1, true>("mfma only", out);
-  run<0, 5, 2, true>("mfma only", out);
+  run<1, 6, 1, true>("ds_read_b128 (unused)", out);
+  run<2, 6, 1, true>("ds_read_b128 (unused)", out);
+  run<4, 6, 1, true>("ds_read_b128 (unused)", out);
+  run<4, 6, 1, false>("ds_read_b128 (unused)", out);
+  run<1, 7, 1, true>("ds_read_b128 -> A operand", out);
   run<4, 0, 1, true>("v_fma_f32", out);
   run<8, 0, 1, true>("v_fma_f32", out);
-  run<12, 0, 1, true>("v_fma_f32", out);
-  run<16, 0, 1, true>("v_fma_f32", out);
-  run<8, 0, 2, true>("v_fma_f32", out);
-  run<16, 0, 1, false>("v_fma_f32", out);
-  run<16, 1, 1, false>("v_pk_fma_f32", out);
-  run<8, 1, 1, true>("v_pk_fma_f32", out);
-  run<16, 2, 1, false>("v_cvt_pk_bf16_f32", out);
-  run<8, 2, 1, true>("v_cvt_pk_bf16_f32", out);
-  run<16, 3, 1, false>("v_exp_f32", out);
-  run<4, 3, 1, true>("v_exp_f32", out);
-  run<8, 4, 1, false>("v_cmp+nop+cndmask", out);
   hipDeviceSynchronize();
   printf("done\n");
   return 0;
