@@ -70,7 +70,8 @@ struct vx_ctx {
 
   // bf16x3 GEMM path (default) for the transformer projections of prefill / NAR; VX_GEMM_F32=1 keeps the fp32 MFMA
   bool x3 = true;
-  bool gemm_ring = true;                      // 256x256 three-stage ring kernel (gemm_bf16x3_ring.hip, k-step-major planes); VX_GEMM_RING=0: older kernels
+  bool gemm_ring = false;                     // VX_GEMM_RING=1: 256x256 three-stage ring kernel (gemm_bf16x3_ring.hip, k-step-major planes).
+                                              // +4 % on the isolated GEMM, no end-to-end gain over the DMA kernel; kept selectable
   bool gemm_dma = true;                       // async-LDS bf16x3 GEMM (gemm_bf16x3_dma.hip); VX_GEMM_DMA=0 keeps the register-staged one
   bool attn_x3 = true;                        // bf16x3 attention (attn_full_x3.hip); VX_ATTN_F32=1 keeps the fp32 MFMA kernel
   unsigned short* fa3 = nullptr;   // activation planes [3][M][K<=4096]
@@ -797,7 +798,7 @@ int vx_finalize_weights(vx_ctx* c) {
   if (const char* ev = getenv("VX_GEMM_F32")) c->x3 = !(ev[0] == '1');
   if (const char* ev = getenv("VX_ATTN_F32")) c->attn_x3 = !(ev[0] == '1');
   if (const char* ev = getenv("VX_GEMM_DMA")) c->gemm_dma = !(ev[0] == '0');
-  if (const char* ev = getenv("VX_GEMM_RING")) c->gemm_ring = !(ev[0] == '0');
+  if (const char* ev = getenv("VX_GEMM_RING")) c->gemm_ring = (ev[0] == '1');
   if (c->x3) {
     auto split_w = [&](const float* Wt, int N, int K, unsigned short** out) -> int {
       if (int e2 = dev_alloc(c, out, (size_t)3 * N * K, false)) return e2;
