@@ -70,3 +70,26 @@ def test_stop_rules_lengths():
     row = dict(text=text, prompt=a[0], enroll=3, prompt_language="en", text_language="en")
     assert m.inference_batch([row], top_k=1)[0].shape[0] == 16 * 7
     assert m.inference_batch([row], top_k=1, force_eos_at=17)[0].shape[0] == 17
+
+
+@pytest.mark.gpu
+def test_attention_kernels_agree():
+    """bf16x3 attention (product path) against the exact-fp32 MFMA kernel on the same scratch data, ragged tail and
+    prefix-LM mask included: fp32-class agreement (both accumulate in fp32; the x3 split is exact to 2^-27)."""
+    import vallex_amd
+    eng = vallex_amd.Engine(num_layers=1, max_batch=1, max_text=8, max_prompt=8, max_new=8, with_vocos=False)
+    for batch, length in ((8, 77), (32, 988)):
+        for causal in (False, True):
+            _, diff = eng.bench_attn(batch, length, causal, 10, 1)
+            assert 0.0 <= diff < 5e-6, (batch, length, causal, diff)
+
+
+@pytest.mark.gpu
+def test_bf16x3_gemm_kernels_agree():
+    """The three bf16x3 GEMM kernels (register-staged, DMA, ring) compute the same sums in the same order: the same
+    difference to the fp32-MFMA kernel, and that difference is at fp32 rounding level for K = 1024 (|x|, |w| <= 1)."""
+    import vallex_amd
+    eng = vallex_amd.Engine(num_layers=1, max_batch=1, max_text=8, max_prompt=8, max_new=8, with_vocos=False)
+    diffs = [eng.bench_gemm(31616, 1024, 1024, k, 1)[1] for k in (1, 2, 3)]
+    assert max(diffs) - min(diffs) <= 1e-6, diffs
+    assert diffs[0] < 5e-4, diffs

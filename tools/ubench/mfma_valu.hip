@@ -14,7 +14,8 @@ constexpr int ITER = 4000;
 // OP: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_cvt_pk_bf16_f32, 3 v_exp_f32, 4 v_cndmask (cmp+cndmask pair), 5 none,
 //     6 ds_read_b128 (conflict-free, results unused but waited for every iteration), 7 ds_read_b128 feeding the MFMA's A operand
 template <int N, int OP, int CHAINS, bool MFMA>
-__global__ __launch_bounds__(256) void k(float* out, int iters) {
+__global__ __launch_bounds__(256) void k(float* out, int iters, unsigned long long* clk) {
+  const unsigned long long c_start = __builtin_readcyclecounter(), r_start = __builtin_amdgcn_s_memrealtime();
   __shared__ __attribute__((aligned(16))) unsigned char lds[16384];
   for (int i = threadIdx.x; i < 4096; i += 256) reinterpret_cast<float*>(lds)[i] = 0.001f * i;
   __syncthreads();
@@ -54,23 +55,32 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
   for (int e = 0; e < 8; ++e) acc += pv[e][0] + pv[e][1];
   for (int e = 0; e < 4; ++e) acc += ld[e][0] + (float)a[e];
   out[blockIdx.x * 256 + threadIdx.x] = acc;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {   // shader-clock cycles and 100 MHz reference ticks spent in this wave
+    clk[0] = __builtin_readcyclecounter() - c_start;
+    clk[1] = __builtin_amdgcn_s_memrealtime() - r_start;
+  }
 }
 
 template <int N, int OP, int CHAINS, bool MFMA>
 void run(const char* name, float* out) {
+  static unsigned long long* clk = nullptr;
+  if (!clk) hipMalloc((void**)&clk, 16);
   for (int wps = 1; wps <= 2; ++wps) {
     const int blocks = 256 * wps;                                // 4 waves per block -> wps waves per SIMD on 256 CUs
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<N, OP, CHAINS, MFMA>), dim3(blocks), dim3(256), 0, 0, out, ITER);
+    hipLaunchKernelGGL((k<N, OP, CHAINS, MFMA>), dim3(blocks), dim3(256), 0, 0, out, ITER, clk);
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((k<N, OP, CHAINS, MFMA>), dim3(blocks), dim3(256), 0, 0, out, ITER);
+    hipLaunchKernelGGL((k<N, OP, CHAINS, MFMA>), dim3(blocks), dim3(256), 0, 0, out, ITER, clk);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    printf("%-28s N=%2d mfma=%d chains=%d waves/SIMD=%d : %7.1f cycles/iter/wave-slot\n", name, N, (int)MFMA, CHAINS, wps,
-           ms * 1e-3 * 2.4e9 / ITER);
+    unsigned long long h[2];
+    hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+    printf("%-28s N=%2d mfma=%d waves/SIMD=%d : %7.1f nominal cycles/iter (2.4 GHz x wall) | wave 0: %.1f s_memtime ticks/iter, %.3f us/iter by s_memrealtime => s_memtime rate %.0f MHz\n",
+           name, N, (int)MFMA, wps, ms * 1e-3 * 2.4e9 / ITER, (double)h[0] / ITER, (double)h[1] / 100.0 / ITER,
+           h[1] ? (double)h[0] / ((double)h[1] / 100.0) : 0.0);
   }
 }
 
@@ -79,13 +89,10 @@ int main() {
   hipMalloc((void**)&out, 512 * 256 * 4);
   run<0, 5, 1, true>("warmup", out);
   run<0, 5, 1, true>("mfma only", out);
-  run<1, 6, 1, true>("ds_read_b128 (unused)", out);
-  run<2, 6, 1, true>("ds_read_b128 (unused)", out);
-  run<4, 6, 1, true>("ds_read_b128 (unused)", out);
-  run<4, 6, 1, false>("ds_read_b128 (unused)", out);
-  run<1, 7, 1, true>("ds_read_b128 -> A operand", out);
   run<4, 0, 1, true>("v_fma_f32", out);
   run<8, 0, 1, true>("v_fma_f32", out);
+  run<16, 0, 1, false>("v_fma_f32", out);
+  run<2, 6, 1, true>("ds_read_b128 (unused)", out);
   hipDeviceSynchronize();
   printf("done\n");
   return 0;

@@ -1478,7 +1478,7 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
   GemmArgs g0{};
   g0.A = A; g0.lda = K; g0.W = Wt; g0.ldw = K; g0.C = C0; g0.ldc = N; g0.M = M; g0.N = N; g0.K = K; g0.act = ACT_NONE;
   launch_gemm_f32(g0, c->stream);
-  if (kernel == 3) {                                             // k-step-major planes for the ring kernel
+  if (kernel == 3 || kernel == 4) {                              // k-step-major planes for the ring kernels
     launch_split3_k16(A, K, M, K, nullptr, A3, (long)M * K, c->stream);
     launch_split3_k16(Wt, K, N, K, nullptr, W3, (long)N * K, c->stream);
   } else {
@@ -1495,6 +1495,7 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
     else if (kernel == 1) launch_gemm_bf16x3(gx, c->stream);
     else if (kernel == 2) launch_gemm_bf16x3_dma(gx, c->stream);
     else if (kernel == 3) launch_gemm_bf16x3_ring(gx, c->stream);
+    else if (kernel == 4) launch_gemm_bf16x3_ring4(gx, c->stream);
     else launch_gemm_bf16x3_probe(gx, kernel - 10, c->stream);      // 11 / 12 / 13: timing probes
   };
   run();
