@@ -16,6 +16,12 @@
 // TRANSPOSED, two keys per ds_write_b32, with the key order inside a row permuted so that the 8 keys one lane contracts
 // in k-step s (the C-layout rows 16 s + 4 hi + {0..3, 8..11} of S^T, which are the P registers 8 s .. 8 s + 7) are one
 // 16-byte run: P never moves between lanes, exactly as in the fp32 kernel.
+//
+// Structure of the tile loop (details at the loop): three LDS buffers (tile t: V, tile t+1: K, tile t+2: being written)
+// and ONE barrier per tile; phase 1 = 24 slots of [1 QK^T MFMA of tile t+1 | a slice of tile t's softmax], phase 2 =
+// 24 slots of [1 PV MFMA of tile t | a slice of the three-way splits of P, of the staged K and of the staged V + their
+// LDS stores]; the slots are instantiated with static_for and every slice is pinned in its slot (pin()).  The kernel is
+// VALU-issue-bound (about 8 VALU instructions per MFMA), see DESIGN.md section 6.
 #include <type_traits>
 
 #include "vx_common.h"
@@ -61,7 +67,6 @@ __device__ __forceinline__ void static_for(F&& f) {
 // pins and the sched_barriers, so neither instruction selection nor the IR sink pass can move the producing arithmetic.
 __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 __device__ __forceinline__ void pin(unsigned& x) { asm volatile("" : "+v"(x)); }
-__device__ __forceinline__ void pin16(f32x16& x) { asm volatile("" : "+v"(x)); }
 
 // (x, y) -> three packed bf16 pairs (x in the low half): w1 + w2 + w3 == (x, y) to 2^-27 relative; pinned.
 // v_cvt_pk_bf16_f32 (RNE) once per term, the bf16 -> f32 widenings are a shift and a mask of the packed word.
