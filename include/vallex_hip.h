@@ -65,7 +65,8 @@ typedef struct vx_batch {
   int32_t batch;
   const int32_t* text_ids;      /* [batch][text_stride]   x: prompt text ids ++ text ids (utils/generation.py:133) */
   const int32_t* text_lang;     /* [batch][text_stride]   per-token MODEL language id en0/zh1/ja2 (models/vallex.py:439-443,
-                                   499-505): first enroll_len entries = prompt_language, rest = text_language */
+                                   499-505): first enroll_len entries = prompt_language, rest = text_language;
+                                   -1 = add no language embedding to that token (VALLE.continual, models/vallex.py:716-729) */
   int32_t text_stride;
   const int32_t* text_lens;     /* [batch]  x_lens */
   const int32_t* prompt_codes;  /* [batch][prompt_stride][8]   y (audio prompt), values 0..1023 */

@@ -63,6 +63,12 @@ CASES = {
                           top_k=1, force_eos_at=24, useed=None),
 }
 
+# VALLE.continual (models/vallex.py:688-787): text ids + a full (T, 8) code matrix; NAR stages only
+CONTINUAL_CASES = {
+    "nl2_continual": dict(num_layers=2, seed=6, eos_gain=1.0, n_text=14, frames=61),          # prefix_len = 30
+    "nl2_continual_long": dict(num_layers=2, seed=7, eos_gain=1.0, n_text=9, frames=470),     # prefix_len = 225 (3 s cap)
+}
+
 CODE2LANG = {0: "zh", 1: "ja", 2: "en"}      # macros.py:15-19 via utils/generation.py:114-115
 
 
@@ -146,8 +152,36 @@ def run_reference(c):
                 nar_logits0=nar_logits[0][0, :16].astype(np.float32))
 
 
+def continual_inputs(c):
+    text = synth.synth_text(c["n_text"], c["seed"])[None]
+    y, _ = synth.synth_prompt(c["frames"], 1, seed=c["seed"] + 100)
+    return text, y
+
+
+def run_reference_continual(c):
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    from models.vallex import VALLE
+
+    m = VALLE(1024, 16, c["num_layers"], norm_first=True, add_prenet=False, prefix_mode=1,
+              share_embedding=True, nar_scale_factor=1.0, prepend_bos=True, num_quantizers=8).eval()
+    sd = synth.vallex_state_dict(c["num_layers"], c["seed"], c["eos_gain"])
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    text, y = continual_inputs(c)
+    with torch.no_grad():
+        codes = m.continual(torch.from_numpy(text).to(torch.int32), torch.IntTensor([text.shape[-1]]),
+                            torch.from_numpy(y).to(torch.int64))
+    return dict(codes=codes.numpy().astype(np.int64))
+
+
 def main(only=None):
     os.makedirs(GOLD, exist_ok=True)
+    for name, c in CONTINUAL_CASES.items():
+        if only and name not in only:
+            continue
+        out = run_reference_continual(c)
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+        print(name, out["codes"].shape, out["codes"][0, :4, 1], flush=True)
     for name, c in CASES.items():
         if only and name not in only:
             continue

@@ -140,15 +140,17 @@ class VallexOracle:
         return self._adaln(x, "nar_decoder.norm", stage_emb)
 
     def _text_embed(self, which, text, enroll, prompt_language, text_language):
-        """models/vallex.py:497-507 (AR) / :622-632 (NAR)."""
+        """models/vallex.py:497-507 (AR) / :622-632 (NAR).  prompt_language = text_language = None: no language embedding
+        (VALLE.continual, models/vallex.py:716-719, 727-729)."""
         x = self.w[f"{which}_text_embedding.word_embeddings.weight"][text].clone()
-        lang = self.w[f"{which}_language_embedding.word_embeddings.weight"]
-        x[:enroll] += lang[LANG_ID[prompt_language]]
-        if isinstance(text_language, str):
-            x[enroll:] += lang[LANG_ID[text_language]]
-        else:
-            ids = torch.tensor([LANG_ID[t] for t in text_language], dtype=torch.long)
-            x[enroll:] += lang[ids]
+        if prompt_language is not None or text_language is not None:
+            lang = self.w[f"{which}_language_embedding.word_embeddings.weight"]
+            x[:enroll] += lang[LANG_ID[prompt_language]]
+            if isinstance(text_language, str):
+                x[enroll:] += lang[LANG_ID[text_language]]
+            else:
+                ids = torch.tensor([LANG_ID[t] for t in text_language], dtype=torch.long)
+                x[enroll:] += lang[ids]
         alpha = self.w[f"{which}_text_position.alpha"]
         return x * 1.0 + alpha * self._pe(x.shape[0])[: x.shape[0]]
 
@@ -301,6 +303,20 @@ class VallexOracle:
                                    top_k, temperature, uniforms, force_eos_at, taps)
         codes = self.nar_generate(text, prompts, gen, int(enroll_x_lens), prompt_language, text_language, taps)
         return codes[None]                                                   # (1, T, 8) int64
+
+    # ---- VALLE.continual (models/vallex.py:688-787, prefix_mode 1 branch :760-784) -------------------------
+    def continual(self, x, x_lens, y) -> np.ndarray:
+        """NAR-only continuation: the first half of `y` (at most 3 s = 225 frames) is the acoustic prompt, the first
+        codebook of the rest is taken as given, codebooks 2..8 of the rest are predicted.  No language embedding is
+        added to the text (unlike `inference`).  Returns (1, T - prefix_len, 8)."""
+        x = np.asarray(x); y = np.asarray(y)
+        assert x.ndim == 2 and y.ndim == 3 and y.shape[0] == 1            # :706-709
+        assert np.all(np.asarray(x_lens) > 0)
+        text = torch.from_numpy(x[0].astype(np.int64))
+        yy = torch.from_numpy(y[0].astype(np.int64))
+        prefix_len = min(int(yy.shape[0] * 0.5), 3 * 75)                  # :722
+        codes = self.nar_generate(text, yy[:prefix_len], yy[prefix_len:, 0].tolist(), 0, None, None)
+        return codes[None]
 
 
 # ---------------------------------------------------------------------------

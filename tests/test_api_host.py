@@ -65,6 +65,39 @@ def test_inference_asserts_like_reference():
         m.inference(x, np.array([0]), y, 2, prompt_language="en", text_language="en")           # x_lens > 0
 
 
+def test_continual_host_logic():
+    """VALLE.continual (models/vallex.py:688-787): signature, asserts, and the batch it hands to the engine (prefix = first
+    half of y capped at 225 frames, first codebook of the rest passed through, language id -1 = no language embedding)."""
+    assert list(inspect.signature(VALLE.continual).parameters) == ["self", "x", "x_lens", "y"]
+    m = _valle(2)
+    x = np.arange(5, 12, dtype=np.int32)[None]
+    y = np.random.default_rng(0).integers(0, 1024, size=(1, 61, 8))
+    with pytest.raises(AssertionError):
+        m.continual(x[0], np.array([7]), y)
+    with pytest.raises(AssertionError):
+        m.continual(x, np.array([7]), y[0])
+    with pytest.raises(AssertionError):
+        m.continual(x, np.array([0]), y)
+
+    seen = {}
+
+    class FakeEngine:                                   # stands in for the HIP engine: records what vx_nar would get
+        def nar(self, batch, codes0):
+            seen["batch"], seen["codes0"] = batch, codes0
+            return [np.zeros((len(codes0[0]), 8), np.int64)]
+
+    m.__dict__["_engine"] = FakeEngine()
+    out = m.continual(x, np.array([7]), y)
+    assert tuple(out.shape) == (1, 31, 8)
+    b = seen["batch"]
+    assert b.n == 1 and b.text_lens[0] == 7 and b.prompt_lens[0] == 30
+    assert (b.text_lang[0, :7] == -1).all() and (b.text_ids[0, :7] == x[0]).all()
+    assert (b.prompt_codes[0, :30] == y[0, :30]).all() and (seen["codes0"][0] == y[0, 30:, 0]).all()
+    y_long = np.zeros((1, 470, 8), np.int64)
+    m.continual(x, np.array([7]), y_long)
+    assert seen["batch"].prompt_lens[0] == 225 and len(seen["codes0"][0]) == 245
+
+
 def test_language_rows_and_model_ids():
     m = _valle(2)
     assert m.language_ID == {"en": 0, "zh": 1, "ja": 2}                     # models/vallex.py:439-443

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import synth
-from oracle.make_golden import CASES
+from oracle.make_golden import CASES, CONTINUAL_CASES, continual_inputs
 from oracle.vallex_oracle import VallexOracle, VocosOracle
 from tests._util import case_row, get_model, golden
 
@@ -254,3 +254,17 @@ def test_engine_rejects_bad_arguments():
     with pytest.raises(vallex_amd.VallexHipError):
         m.inference_batch([dict(text=t[0], prompt=a[0], enroll=3, prompt_language="en", text_language="en")], top_k=1,
                           temperature=0.0)
+
+
+@pytest.mark.xfail(strict=False, reason="written after this round's GPU budget was spent; the oracle side is pinned to the live "
+                                        "reference on CPU (test_oracle_golden.py), the first hardware run is the round-end one")
+@pytest.mark.parametrize("name", sorted(CONTINUAL_CASES))
+def test_continual_matches_reference(name):
+    """`VALLE.continual` (models/vallex.py:688-787) through vx_nar with language id -1 (= no language embedding):
+    bit-exact ids against the live reference's own continual() output."""
+    c = CONTINUAL_CASES[name]
+    m = get_model(c["num_layers"], c["seed"], c["eos_gain"])
+    text, y = continual_inputs(c)
+    out = m.continual(text, np.array([text.shape[-1]]), y)
+    out = out.numpy() if hasattr(out, "numpy") else out
+    np.testing.assert_array_equal(out, golden(name)["codes"])

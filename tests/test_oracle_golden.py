@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import synth
-from oracle.make_golden import CASES, GOLD, case_inputs
+from oracle.make_golden import CASES, CONTINUAL_CASES, GOLD, case_inputs, continual_inputs
 from oracle.vallex_oracle import VallexOracle
 
 FAST = [n for n in CASES if n.startswith("nl2_")]
@@ -52,3 +52,18 @@ def test_synthetic_state_dict_layout():
     n_ar = sum(v.size for k, v in sd.items() if k.startswith("ar_decoder."))
     assert n_ar == 151_156_736
     assert sd["nar_predict_layers.0.weight"] is sd["nar_audio_embeddings.2.word_embeddings.weight"]
+
+
+@pytest.mark.parametrize("name", sorted(CONTINUAL_CASES))
+def test_oracle_continual_matches_reference(name):
+    """VALLE.continual (models/vallex.py:688-787): NAR-only continuation, no language embedding, prefix = first half of y
+    capped at 225 frames.  Golden = the live reference's own continual()."""
+    c = CONTINUAL_CASES[name]
+    g = np.load(os.path.join(GOLD, name + ".npz"))["codes"]
+    orc = VallexOracle(synth.vallex_state_dict(c["num_layers"], c["seed"], c["eos_gain"]), c["num_layers"])
+    text, y = continual_inputs(c)
+    out = orc.continual(text, np.array([text.shape[-1]]), y)
+    prefix_len = min(int(y.shape[1] * 0.5), 225)
+    assert out.shape == g.shape == (1, y.shape[1] - prefix_len, 8)
+    np.testing.assert_array_equal(out, g)
+    np.testing.assert_array_equal(out[0, :, 0], y[0, prefix_len:, 0])      # first codebook is passed through

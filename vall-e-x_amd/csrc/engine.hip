@@ -292,7 +292,7 @@ int check_batch(vx_ctx* c, const vx_batch* b, int max_rows) {
     for (int s = 0; s < S; ++s) {
       const int id = b->text_ids[(long)i * b->text_stride + s], lg = b->text_lang[(long)i * b->text_stride + s];
       if (id < 0 || id >= 2048) FAIL(VX_EINVAL, "row %d: text id %d out of range", i, id);
-      if (lg < 0 || lg > 2) FAIL(VX_EINVAL, "row %d: language id %d out of range", i, lg);
+      if (lg < -1 || lg > 2) FAIL(VX_EINVAL, "row %d: language id %d out of range", i, lg);   // -1: no language embedding
     }
     for (int t = 0; t < Tp * N_Q; ++t) {
       const int v = b->prompt_codes[(long)i * b->prompt_stride * N_Q + t];

@@ -204,6 +204,25 @@ class VALLE:
         out = codes[None]
         return torch.from_numpy(out) if torch is not None else out
 
+    def continual(self, x, x_lens, y):
+        """`VALLE.continual` (models/vallex.py:688-787): NAR-only continuation.  The first half of `y` (1, T, 8) -- at most
+        3 s = 225 frames -- is the acoustic prompt, the first codebook of the remaining frames is taken as given and
+        codebooks 2..8 of those frames are predicted; the text gets NO language embedding on this path.
+        Returns (1, T - prefix_len, 8) like the reference."""
+        xa, xl, ya = _np(x), _np(x_lens), _np(y)
+        assert xa.ndim == 2, xa.shape                      # models/vallex.py:706-712
+        assert xl.ndim == 1, xl.shape
+        assert ya.ndim == 3, ya.shape
+        assert ya.shape[0] == 1, ya.shape
+        assert np.all(xl > 0)
+        S = int(xl.max())
+        prefix_len = min(int(ya.shape[1] * 0.5), 3 * 75)   # :722
+        text = _np(xa[0, :S], np.int32)
+        batch = Batch([text], [np.full(S, -1, np.int32)], [_np(ya[0, :prefix_len], np.int32).reshape(-1, 8)])
+        codes = self.engine.nar(batch, [_np(ya[0, prefix_len:, 0], np.int32)])[0]
+        out = codes[None]
+        return torch.from_numpy(out) if torch is not None else out
+
     def inference_batch(self, rows: Sequence[dict], top_k: int = -100, temperature: float = 1.0, uniforms=None,
                         force_eos_at=None, seed: int = 0, sync_every: int = 8, best_of: int = 1,
                         length_penalty: float = 1.0, return_worst: bool = False) -> List[np.ndarray]:
