@@ -1453,7 +1453,8 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
 }
 
 // Stand-alone GEMM micro-benchmark on scratch buffers (kernel development aid; never on the product path):
-// kernel 0 = gemm_f32, 1 = gemm_bf16x3, 2 = gemm_bf16x3_dma, 3 = gemm_bf16x3_ring.  Reports the average launch time and the max abs
+// kernel 0 = gemm_f32, 1 = gemm_bf16x3, 2 = gemm_bf16x3_dma, 3 = gemm_bf16x3_ring, 4 = ring4, 5 = pipe;
+// 11-13 / 21-24 = timing probes of the register-staged / DMA kernel (results meaningless).  Reports the average launch time and the max abs
 // difference of the first 256 output rows against the fp32-MFMA kernel.
 int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, int32_t reps, double* avg_us,
                   double* max_abs_diff) {
@@ -1501,6 +1502,7 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
     else if (kernel == 3) launch_gemm_bf16x3_ring(gx, c->stream);
     else if (kernel == 4) launch_gemm_bf16x3_ring4(gx, c->stream);
     else if (kernel == 5) launch_gemm_bf16x3_pipe(gx, c->stream);
+    else if (kernel >= 21) launch_gemm_bf16x3_dma_probe(gx, kernel - 20, c->stream);   // 21-24: probes of the DMA kernel
     else launch_gemm_bf16x3_probe(gx, kernel - 10, c->stream);      // 11 / 12 / 13: timing probes
   };
   run();

@@ -37,6 +37,10 @@ typedef void __attribute__((address_space(3)))* lptr_t;
 
 }  // namespace
 
+// V = 0 product kernel.  Timing probes (tools/gemm_bench.py, results meaningless): V = 1 no DMA after the first two tiles
+// (compute + fragment reads + barriers only); V = 2 no MFMAs; V = 3 fragments read once (MFMAs on stale registers);
+// V = 4 no barriers / vmcnt waits (racy).
+template <int V>
 __global__ __launch_bounds__(512, 1) void gemm_bf16x3_dma_kernel(GemmX3Args g) {
   __shared__ __attribute__((aligned(1024))) unsigned char stage0[STAGE];
   __shared__ __attribute__((aligned(1024))) unsigned char stage1[STAGE];
@@ -120,34 +124,42 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_dma_kernel(GemmX3Args g) {
         const int pw = t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0;   // w3 a1, w1 a3, w2 a2, w2 a1, w1 a2, w1 a1
         const int pa = t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0;
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
-          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[pw][jn], a[i][pa], acc[i][jn], 0, 0, 0);
+        for (int jn = 0; jn < 2; ++jn) {
+          if (V == 2) acc[i][jn][0] += (float)w[pw][jn][0] * (float)a[i][pa][0];
+          else acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[pw][jn], a[i][pa], acc[i][jn], 0, 0, 0);
+        }
       }
     }
   };
   // One K tile.  The next tile's DMA goes out FIRST: its landing time, not the LDS latency of the first fragments, is
   // what the barrier at the top of the next tile waits for (issuing it behind the fragment reads cost 6 %).
-  auto ktile = [&](const unsigned char* stage, unsigned char* other, int kt_next, bool more) {
-    bf16x8 w0[3][2], a0[2][3], w1[3][2], a1[2][3];
-    if (more) dma(other, kt_next);
-    frags(stage, 0, w0, a0);
-    frags(stage, 1, w1, a1);
+  bf16x8 w0[3][2], a0[2][3], w1[3][2], a1[2][3];
+  auto ktile = [&](const unsigned char* stage, unsigned char* other, int kt_next, bool more, bool first) {
+    if (more && (V != 1 || kt_next < 2)) dma(other, kt_next);
+    if (V != 3 || first) {
+      frags(stage, 0, w0, a0);
+      frags(stage, 1, w1, a1);
+    }
     mfmas(w0, a0);
     mfmas(w1, a1);
+  };
+  auto rendezvous = [&]() {
+    if (V == 4) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   };
 
   const int nk = g.K / DK;
   dma(stage0, 0);
   for (int kt = 0; kt < nk; kt += 2) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    ktile(stage0, stage1, kt + 1, kt + 1 < nk);
+    rendezvous();
+    ktile(stage0, stage1, kt + 1, kt + 1 < nk, kt == 0);
     if (kt + 1 < nk) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      ktile(stage1, stage0, kt + 2, kt + 2 < nk);
+      rendezvous();
+      ktile(stage1, stage0, kt + 2, kt + 2 < nk, false);
     }
   }
+  if (V == 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
 
   // epilogue: acc[i][jn][4*g4 + e] = C[m0 + wm*64 + i*32 + l31][n0 + wn*64 + jn*32 + 8*g4 + 4*hi + e]
 #pragma unroll
@@ -192,7 +204,17 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_dma_kernel(GemmX3Args g) {
 void launch_gemm_bf16x3_dma(const GemmX3Args& g, hipStream_t s) {
   const int tiles = ((g.M + DM - 1) / DM) * ((g.N + DN - 1) / DN);
   if (tiles <= 0) return;
-  hipLaunchKernelGGL(gemm_bf16x3_dma_kernel, dim3(tiles), dim3(512), 0, s, g);
+  hipLaunchKernelGGL(gemm_bf16x3_dma_kernel<0>, dim3(tiles), dim3(512), 0, s, g);
+}
+
+void launch_gemm_bf16x3_dma_probe(const GemmX3Args& g, int variant, hipStream_t s) {
+  const int tiles = ((g.M + DM - 1) / DM) * ((g.N + DN - 1) / DN);
+  if (tiles <= 0) return;
+  const dim3 grid(tiles), block(512);
+  if (variant == 1) hipLaunchKernelGGL(gemm_bf16x3_dma_kernel<1>, grid, block, 0, s, g);
+  else if (variant == 2) hipLaunchKernelGGL(gemm_bf16x3_dma_kernel<2>, grid, block, 0, s, g);
+  else if (variant == 3) hipLaunchKernelGGL(gemm_bf16x3_dma_kernel<3>, grid, block, 0, s, g);
+  else hipLaunchKernelGGL(gemm_bf16x3_dma_kernel<4>, grid, block, 0, s, g);
 }
 
 }  // namespace vx

@@ -52,6 +52,7 @@ struct GemmX3Args {
 void launch_gemm_bf16x3(const GemmX3Args& g, hipStream_t s);
 void launch_gemm_bf16x3_probe(const GemmX3Args& g, int variant, hipStream_t s);
 void launch_gemm_bf16x3_dma(const GemmX3Args& g, hipStream_t s);
+void launch_gemm_bf16x3_dma_probe(const GemmX3Args& g, int variant, hipStream_t s);   // timing probes 1-4 (tools/gemm_bench.py)
 // gemm_bf16x3_ring.hip: 256x256 tile, k-step stages, 3-deep async ring; planes in k-step-major order [K/16][rows][16]
 void launch_gemm_bf16x3_ring(const GemmX3Args& g, hipStream_t s);
 void launch_gemm_bf16x3_ring4(const GemmX3Args& g, hipStream_t s);
