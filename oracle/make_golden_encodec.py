@@ -12,7 +12,8 @@ import os
 import numpy as np
 import torch
 
-from .encodec_oracle import NQ, RATIOS, EncodecDecoderOracle, encodec_state_dict
+from .encodec_oracle import (NQ, RATIOS, EncodecDecoderOracle, EncodecEncoderOracle, encodec_encoder_state_dict,
+                             encodec_state_dict)
 
 GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 CASES = {"encodec_T37": (2, 37, 11), "encodec_T5": (1, 5, 12)}       # name -> (B, T, seed); T=5 exercises the short-pad path
@@ -23,7 +24,20 @@ def case_codes(name):
     return np.random.default_rng(seed).integers(0, 1024, size=(B, T, NQ), dtype=np.int64)
 
 
-def load_into_transformers(sd):
+# encoder cases: name -> (B, samples, seed); 7777 is not a multiple of the 320-sample hop (exercises the right padding)
+ENC_CASES = {"encodec_enc_12000": (2, 12000, 21), "encodec_enc_7777": (1, 7777, 22)}
+
+
+def case_wav(name):
+    B, L, seed = ENC_CASES[name]
+    rng = np.random.default_rng(seed)
+    t = np.arange(L, dtype=np.float32) / 24000.0
+    f0 = rng.uniform(90.0, 400.0, size=(B, 1)).astype(np.float32)
+    wav = 0.3 * np.sin(2 * np.pi * f0 * t[None]) + 0.1 * rng.standard_normal((B, L)).astype(np.float32)
+    return wav.astype(np.float32)
+
+
+def load_into_transformers(sd, enc=None):
     from transformers import EncodecConfig, EncodecModel
     m = EncodecModel(EncodecConfig()).eval()
     tsd = m.state_dict()
@@ -50,6 +64,17 @@ def load_into_transformers(sd):
         idx += 3
     put_wn("decoder.layers.15.conv", sd["decoder.15.weight"])
     tsd["decoder.layers.15.conv.bias"] = torch.from_numpy(sd["decoder.15.bias"])
+    if enc is not None:
+        for i in (0, 3, 6, 9, 12, 15):
+            put_wn(f"encoder.layers.{i}.conv", enc[f"encoder.{i}.weight"])
+            tsd[f"encoder.layers.{i}.conv.bias"] = torch.from_numpy(enc[f"encoder.{i}.bias"])
+        for i in (1, 4, 7, 10):
+            for mine, theirs in (("block1", "block.1"), ("block3", "block.3"), ("shortcut", "shortcut")):
+                put_wn(f"encoder.layers.{i}.{theirs}.conv", enc[f"encoder.{i}.{mine}.weight"])
+                tsd[f"encoder.layers.{i}.{theirs}.conv.bias"] = torch.from_numpy(enc[f"encoder.{i}.{mine}.bias"])
+        for l in range(2):
+            for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+                tsd[f"encoder.layers.13.lstm.{n}_l{l}"] = torch.from_numpy(enc[f"encoder.13.lstm.{n}_l{l}"])
     m.load_state_dict(tsd, strict=True)
     return m
 
@@ -67,5 +92,21 @@ def main():
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), audio=ref.astype(np.float32))
 
 
+def main_encoder():
+    sd, enc = encodec_state_dict(3), encodec_encoder_state_dict(4)
+    m = load_into_transformers(sd, enc)
+    orc = EncodecEncoderOracle(enc, sd)
+    for name in ENC_CASES:
+        wav = case_wav(name)
+        with torch.no_grad():
+            ref = m.encode(torch.from_numpy(wav)[:, None, :], bandwidth=6.0)[0][0].permute(0, 2, 1).numpy()   # (B, T, 8)
+            emb = m.encoder(torch.from_numpy(wav)[:, None, :]).numpy()
+        mine = orc.encode(wav)
+        print(name, ref.shape, "codes equal:", bool((ref == mine).all()), "embedding max |err|",
+              float(np.abs(emb - orc.embeddings(wav).numpy()).max()))
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), codes=ref.astype(np.int64), emb=emb[:, :, :4].astype(np.float32))
+
+
 if __name__ == "__main__":
+    main_encoder()
     main()

@@ -6,8 +6,9 @@ import numpy as np
 import pytest
 
 import vallex_amd  # noqa: F401
-from oracle.encodec_oracle import EncodecDecoderOracle, encodec_state_dict
-from oracle.make_golden_encodec import CASES, GOLD, case_codes
+from oracle.encodec_oracle import (EncodecDecoderOracle, EncodecEncoderOracle, encodec_encoder_state_dict,
+                                   encodec_state_dict)
+from oracle.make_golden_encodec import CASES, ENC_CASES, GOLD, case_codes, case_wav
 from vallex_amd.data.tokenizer import AudioTokenizer, canonical_encodec_state_dict
 
 
@@ -17,6 +18,37 @@ def test_oracle_matches_transformers_port(name):
     out = EncodecDecoderOracle(encodec_state_dict(3)).decode(case_codes(name))
     assert out.shape == g.shape
     np.testing.assert_allclose(out, g, atol=1e-6, rtol=0)
+
+
+@pytest.mark.parametrize("name", list(ENC_CASES))
+def test_encoder_oracle_matches_transformers_port(name):
+    """SEANet encoder + RVQ encode (prompt enrolment, data/tokenizer.py:92-111): the oracle's codes are
+    bit-exact against `transformers.EncodecModel.encode(bandwidth=6.0)`, its embeddings agree to fp32 rounding."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    orc = EncodecEncoderOracle(encodec_encoder_state_dict(4), encodec_state_dict(3))
+    wav = case_wav(name)
+    emb = orc.embeddings(wav)
+    assert emb.shape[-1] == -(-wav.shape[-1] // 320)                   # T = ceil(L / hop)
+    np.testing.assert_allclose(emb[:, :, :4].numpy(), g["emb"], atol=1e-6, rtol=0)
+    codes = orc.quantize(emb)
+    assert codes.shape == g["codes"].shape
+    np.testing.assert_array_equal(codes, g["codes"])
+
+
+def test_rvq_codes_are_nearest_neighbours():
+    """Domain property of the RVQ (size independent): code q of every frame is the codeword nearest to the residual left
+    by codebooks 0..q-1 (checked in float64 against the brute-force distance), i.e. encode is greedy residual quantisation."""
+    dec_sd = encodec_state_dict(3)
+    orc = EncodecEncoderOracle(encodec_encoder_state_dict(4), dec_sd)
+    emb = orc.embeddings(case_wav("encodec_enc_7777"))
+    codes = orc.quantize(emb)                                           # (B, T, 8)
+    residual = emb.numpy().astype(np.float64)[0].T                      # (T, 128)
+    for q in range(8):
+        e = dec_sd[f"quantizer.{q}.embed"].astype(np.float64)           # (1024, 128)
+        d = ((residual[:, None, :] - e[None]) ** 2).sum(-1)             # (T, 1024)
+        chosen = d[np.arange(d.shape[0]), codes[0, :, q]]
+        assert np.all(chosen <= d.min(1) + 1e-4)                        # fp32 distance ties within rounding
+        residual = residual - e[codes[0, :, q]]
 
 
 def test_state_dict_normalisation_folds_weight_norm():
