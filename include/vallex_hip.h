@@ -112,6 +112,14 @@ int vx_vocos_decode(vx_ctx* ctx, const int64_t* codes, int32_t codes_stride, con
 int vx_encodec_decode(vx_ctx* ctx, const int64_t* codes, int32_t codes_stride, const int32_t* lens, int32_t batch,
                       float* audio, int64_t audio_stride);
 
+/* replaces: AudioTokenizer.encode(wav) -> codec.encode (EnCodec 24 kHz SEANet encoder + residual vector quantiser at 6 kbps,
+ * 8 codebooks), data/tokenizer.py:92-111 -- the prompt-enrolment path (tokenize_audio, utils/prompt_making.py:57-84).
+ * Needs the decoder tensors plus "encodec.encoder." + {0,3,6,9,12,15}.{weight,bias}, {1,4,7,10}.{block1,block3,shortcut}.{weight,
+ * bias}, 13.lstm.* (weight-norm folded).  wav [batch][wav_stride] fp32 mono 24 kHz, lens [batch] samples;
+ * codes [batch][codes_stride][8] int64, out_lens [batch] = ceil(len / 320) frames. */
+int vx_encodec_encode(vx_ctx* ctx, const float* wav, int64_t wav_stride, const int32_t* lens, int32_t batch, int64_t* codes,
+                      int32_t codes_stride, int32_t* out_lens);
+
 /* ---- step-level entries (kernel-level parity tests; same kernels as vx_infer) ---------------------------- */
 /* first ar_decoder.infer call (models/vallex.py:528-562): embeds, runs the prefix-LM prefill, fills the KV arena,
  * leaves the logits of the last row available.  batch <= 32. */

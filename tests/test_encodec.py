@@ -101,3 +101,61 @@ def test_hip_decoder_matches_transformers_port():
     both = m.engine.encodec_decode([c0, c1])
     np.testing.assert_allclose(both[1], np.load(os.path.join(GOLD, "encodec_T5.npz"))["audio"][0], atol=2e-5, rtol=0)
     np.testing.assert_allclose(both[0], np.load(os.path.join(GOLD, "encodec_T37.npz"))["audio"][0], atol=2e-5, rtol=0)
+
+
+def test_canonical_state_dict_covers_the_encoder():
+    """transformers-port names (parametrised weight-norm) of encoder + decoder -> the canonical folded names the C ABI loads."""
+    from oracle.make_golden_encodec import load_into_transformers
+    dec, enc = encodec_state_dict(3), encodec_encoder_state_dict(4)
+    tsd = load_into_transformers(dec, enc).state_dict()
+    canon = canonical_encodec_state_dict(tsd)
+    want = dict(dec)
+    want.update(enc)
+    assert set(canon) == set(want)
+    for k in want:
+        np.testing.assert_allclose(canon[k], want[k], atol=1e-6, rtol=1e-6)
+
+
+def _codes_agree_up_to_ties(got, gold, emb, dec_sd, tol=1e-3):
+    """RVQ codes can legitimately differ from another fp32 implementation where two codewords are (nearly) equidistant
+    (the GEMM summation order decides).  Accept a frame if its codes are equal, or if at the FIRST differing codebook both
+    candidates are within `tol` (relative) of the minimum distance in float64; later codebooks of that frame then differ
+    by construction and are not compared.  Returns the number of frames that used the tie rule."""
+    ties = 0
+    T = gold.shape[0]
+    for t in range(T):
+        if (got[t] == gold[t]).all():
+            continue
+        q = int(np.argmax(got[t] != gold[t]))
+        r = emb[:, t].astype(np.float64)
+        for j in range(q):
+            r = r - dec_sd[f"quantizer.{j}.embed"][gold[t, j]].astype(np.float64)
+        e = dec_sd[f"quantizer.{q}.embed"].astype(np.float64)
+        d = ((r[None] - e) ** 2).sum(1)
+        assert d[got[t, q]] <= d.min() * (1 + tol) + 1e-9, (t, q, d[got[t, q]], d.min())
+        ties += 1
+    return ties
+
+
+@pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason="vx_encodec_encode was written after this round's GPU budget was spent: the oracle is pinned on "
+                                        "CPU, the first hardware run of the HIP encoder is the round-end one")
+def test_hip_encoder_matches_transformers_port():
+    from tests._util import get_model
+    m = get_model(2, 0, 2.5, max_new=64, max_batch=4)
+    dec = encodec_state_dict(3)
+    sd = dict(dec)
+    sd.update(encodec_encoder_state_dict(4))
+    m.load_encodec_state_dict(sd)
+    tok = AudioTokenizer(device="cuda:0", valle=m)
+    orc = EncodecEncoderOracle(encodec_encoder_state_dict(4), dec)
+    for name in ENC_CASES:
+        wav = case_wav(name)                                            # (B, L)
+        gold = np.load(os.path.join(GOLD, name + ".npz"))["codes"]      # (B, T, 8)
+        frames = tok.encode(wav[:, None, :])
+        assert len(frames) == 1 and frames[0][1] is None
+        got = np.transpose(np.asarray(frames[0][0]), (0, 2, 1))         # (B, 8, T) -> (B, T, 8)
+        assert got.shape == gold.shape
+        emb = orc.embeddings(wav).numpy()
+        ties = sum(_codes_agree_up_to_ties(got[b], gold[b], emb[b], dec) for b in range(got.shape[0]))
+        assert ties <= max(1, gold.shape[0] * gold.shape[1] // 10), ties  # a few near-ties at most

@@ -45,7 +45,8 @@ class vx_sampling(C.Structure):
 
 # every symbol include/vallex_hip.h declares (tests/test_abi.py checks the library exports exactly these)
 SYMBOLS = ["vx_create", "vx_destroy", "vx_last_error", "vx_synchronize", "vx_load_tensor", "vx_finalize_weights",
-           "vx_infer", "vx_vocos_decode", "vx_encodec_decode", "vx_ar_prefill", "vx_ar_logits", "vx_ar_step", "vx_nar", "vx_read_tap",
+           "vx_infer", "vx_vocos_decode", "vx_encodec_decode", "vx_encodec_encode", "vx_ar_prefill", "vx_ar_logits", "vx_ar_step",
+           "vx_nar", "vx_read_tap",
            "vx_prof_enable", "vx_prof_get", "vx_prof_reset", "vx_bench_kernel", "vx_bench_gemm", "vx_bench_attn", "vx_last_stats"]
 
 _lib = None
@@ -74,6 +75,8 @@ def load_library() -> C.CDLL:
     lib.vx_vocos_decode.argtypes = [ctx, P(C.c_int64), C.c_int32, P(C.c_int32), C.c_int32, C.c_int32, P(C.c_float),
                                     C.c_int64]
     lib.vx_encodec_decode.argtypes = [ctx, P(C.c_int64), C.c_int32, P(C.c_int32), C.c_int32, P(C.c_float), C.c_int64]
+    lib.vx_encodec_encode.argtypes = [ctx, P(C.c_float), C.c_int64, P(C.c_int32), C.c_int32, P(C.c_int64), C.c_int32,
+                                      P(C.c_int32)]
     lib.vx_ar_prefill.argtypes = [ctx, P(vx_batch)]
     lib.vx_ar_logits.argtypes = [ctx, P(C.c_float)]
     lib.vx_ar_step.argtypes = [ctx, P(C.c_int32)]
@@ -219,6 +222,21 @@ class Engine:
         self._chk(self.lib.vx_encodec_decode(self.ctx, _ptr(buf, C.c_int64), stride, _ptr(lens, C.c_int32), n,
                                              _ptr(audio, C.c_float), stride * 320))
         return [audio[i, : lens[i] * 320].copy() for i in range(n)]
+
+    def encodec_encode(self, wavs: Sequence[np.ndarray]):
+        """mono 24 kHz fp32 waveforms (L_i,) -> codes (ceil(L_i / 320), 8) int64 per row (EnCodec encoder + RVQ, 6 kbps)."""
+        n = len(wavs)
+        lens = np.array([len(w) for w in wavs], np.int32)
+        stride = max(1, int(lens.max()))
+        buf = np.zeros((n, stride), np.float32)
+        for i, w in enumerate(wavs):
+            buf[i, : len(w)] = np.asarray(w, np.float32)
+        cstride = (stride + 319) // 320
+        codes = np.zeros((n, cstride, 8), np.int64)
+        out_lens = np.zeros(n, np.int32)
+        self._chk(self.lib.vx_encodec_encode(self.ctx, _ptr(buf, C.c_float), stride, _ptr(lens, C.c_int32), n,
+                                             _ptr(codes, C.c_int64), cstride, _ptr(out_lens, C.c_int32)))
+        return [codes[i, : out_lens[i]].copy() for i in range(n)]
 
     # ---- step-level (tests) ----
     def ar_prefill(self, batch: Batch):

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <map>
 #include <string>
 #include <vector>
@@ -118,6 +119,11 @@ struct vx_ctx {
         *ec_a = nullptr, *ec_sc = nullptr, *ec_out = nullptr, *ec_h = nullptr, *ec_audio = nullptr, *ec_hp = nullptr,
         *ec_c = nullptr, *ec_pg = nullptr;
   long ec_frames_cap = 0;
+  // EnCodec SEANet encoder + RVQ encode (prompt enrolment; shares the decoder's arena)
+  bool has_encodec_enc = false;
+  float *en_w1[4] = {}, *en_w3[4] = {}, *en_wd[4] = {}, *en_w15 = nullptr, *en_lstm_b[2] = {nullptr, nullptr},
+        *en_whh_p[2] = {nullptr, nullptr}, *en_e2 = nullptr, *en_scores = nullptr;
+  long long* en_codes = nullptr;
 
   // vocos arena
   float *vfeat = nullptr, *vcol = nullptr, *vx0 = nullptr, *vx1 = nullptr, *vhid = nullptr, *vo = nullptr,
@@ -1054,6 +1060,102 @@ int vx_finalize_weights(vx_ctx* c) {
     if ((e = dev_alloc(c, &c->ec_c, (size_t)MB * 512))) return e;
     if ((e = dev_alloc(c, &c->ec_pg, (size_t)2 * MB * 2048))) return e;
     c->has_encodec = true;
+    // ---- encoder + RVQ encode (optional: needs the "encodec.encoder.*" tensors; data/tokenizer.py:92-111 path) ----
+    if (c->w.count("encodec.encoder.0.weight")) {
+      const int eratios[4] = {2, 4, 5, 8};
+#define NEED(...) if ((e = need(c, __VA_ARGS__))) return e
+      NEED("encodec.encoder.0.weight", {32, 1, 7});
+      NEED("encodec.encoder.0.bias", {32});
+      {
+        int C = 32;
+        for (int st = 0; st < 4; ++st) {
+          const int r = eratios[st];
+          const std::string pR = "encodec.encoder." + std::to_string(1 + 3 * st), pD = "encodec.encoder." + std::to_string(3 + 3 * st);
+          NEED(pR + ".block1.weight", {C / 2, C, 3});
+          NEED(pR + ".block1.bias", {C / 2});
+          NEED(pR + ".block3.weight", {C, C / 2, 1});
+          NEED(pR + ".block3.bias", {C});
+          NEED(pR + ".shortcut.weight", {C, C, 1});
+          NEED(pR + ".shortcut.bias", {C});
+          NEED(pD + ".weight", {2 * C, C, 2 * r});
+          NEED(pD + ".bias", {2 * C});
+          C *= 2;
+        }
+      }
+      for (int l = 0; l < 2; ++l) {
+        const std::string sfx = "_l" + std::to_string(l);
+        NEED("encodec.encoder.13.lstm.weight_ih" + sfx, {2048, 512});
+        NEED("encodec.encoder.13.lstm.weight_hh" + sfx, {2048, 512});
+        NEED("encodec.encoder.13.lstm.bias_ih" + sfx, {2048});
+        NEED("encodec.encoder.13.lstm.bias_hh" + sfx, {2048});
+      }
+      NEED("encodec.encoder.15.weight", {128, 512, 7});
+      NEED("encodec.encoder.15.bias", {128});
+#undef NEED
+      {
+        int C = 32;
+        for (int st = 0; st < 4; ++st) {
+          const int r = eratios[st], K = 2 * r;
+          const std::string pR = "encodec.encoder." + std::to_string(1 + 3 * st), pD = "encodec.encoder." + std::to_string(3 + 3 * st);
+          // resblock conv k3 (C/2, C, 3) -> [C/2][tap*C + c]
+          if ((e = fetch(pR + ".block1.weight", w))) return e;
+          w2.assign((size_t)(C / 2) * 3 * C, 0.f);
+          for (int o = 0; o < C / 2; ++o)
+            for (int ch = 0; ch < C; ++ch)
+              for (int tap = 0; tap < 3; ++tap) w2[(size_t)o * 3 * C + tap * C + ch] = w[((size_t)o * C + ch) * 3 + tap];
+          if ((e = upload(w2, &c->en_w1[st]))) return e;
+          // resblock conv k1 (C, C/2, 1) -> [C][ldh], ldh = max(C/2, 32)
+          const int ldh = std::max(C / 2, 32);
+          if ((e = fetch(pR + ".block3.weight", w))) return e;
+          w2.assign((size_t)C * ldh, 0.f);
+          for (int o = 0; o < C; ++o)
+            for (int ch = 0; ch < C / 2; ++ch) w2[(size_t)o * ldh + ch] = w[(size_t)o * (C / 2) + ch];
+          if ((e = upload(w2, &c->en_w3[st]))) return e;
+          // strided conv (2C, C, 2r) -> [2C][tap*C + c]: the window of an output frame is 2r consecutive channels-last rows
+          if ((e = fetch(pD + ".weight", w))) return e;
+          w2.assign((size_t)2 * C * K * C, 0.f);
+          for (int o = 0; o < 2 * C; ++o)
+            for (int ch = 0; ch < C; ++ch)
+              for (int tap = 0; tap < K; ++tap) w2[(size_t)o * K * C + tap * C + ch] = w[((size_t)o * C + ch) * K + tap];
+          if ((e = upload(w2, &c->en_wd[st]))) return e;
+          C *= 2;
+        }
+      }
+      for (int l = 0; l < 2; ++l) {
+        const std::string sfx = "_l" + std::to_string(l);
+        if ((e = fetch("encodec.encoder.13.lstm.bias_ih" + sfx, b))) return e;
+        if ((e = fetch("encodec.encoder.13.lstm.bias_hh" + sfx, b2))) return e;
+        for (size_t i = 0; i < b.size(); ++i) b[i] += b2[i];
+        if ((e = upload(b, &c->en_lstm_b[l]))) return e;
+        if ((e = pack(c, W(c, "encodec.encoder.13.lstm.weight_hh" + sfx), 2048, 512, 2048, &c->en_whh_p[l]))) return e;
+      }
+      // last conv (128, 512, 7) -> [128][tap*512 + c]
+      if ((e = fetch("encodec.encoder.15.weight", w))) return e;
+      w2.assign((size_t)128 * 3584, 0.f);
+      for (int o = 0; o < 128; ++o)
+        for (int ch = 0; ch < 512; ++ch)
+          for (int tap = 0; tap < 7; ++tap) w2[(size_t)o * 3584 + tap * 512 + ch] = w[((size_t)o * 512 + ch) * 7 + tap];
+      if ((e = upload(w2, &c->en_w15))) return e;
+      // |e_c|^2 of every codeword (EncodecEuclideanCodebook.quantize: embed.pow(2).sum(0))
+      b.assign((size_t)N_Q * 1024, 0.f);
+      for (int q = 0; q < N_Q; ++q) {
+        if ((e = fetch("encodec.quantizer." + std::to_string(q) + ".embed", w))) return e;
+        for (int cw = 0; cw < 1024; ++cw) {
+          float acc = 0.f;
+          for (int k = 0; k < 128; ++k) acc += w[(size_t)cw * 128 + k] * w[(size_t)cw * 128 + k];
+          b[(size_t)q * 1024 + cw] = acc;
+        }
+      }
+      if ((e = upload(b, &c->en_e2))) return e;
+      if ((e = dev_alloc(c, &c->en_scores, Fc * 1024))) return e;
+      {
+        void* qp = nullptr;
+        HIPCHK(hipMalloc(&qp, Fc * 8 * sizeof(long long)));
+        c->allocs.push_back(qp);
+        c->en_codes = reinterpret_cast<long long*>(qp);
+      }
+      c->has_encodec_enc = true;
+    }
   }
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipGetLastError());
@@ -1347,6 +1449,111 @@ int vx_encodec_decode(vx_ctx* c, const int64_t* codes, int32_t codes_stride, con
                             (size_t)seq_len[i] * 320 * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
+  }
+  return VX_OK;
+}
+
+// replaces: AudioTokenizer.encode -> codec.encode(wav) (data/tokenizer.py:92-111, called by tokenize_audio for prompt
+// enrolment, utils/prompt_making.py:57-84): EnCodec 24 kHz SEANet encoder + residual VQ at 6 kbps (8 codebooks).
+// wav [batch][wav_stride] fp32 mono 24 kHz, lens [batch] samples -> codes [batch][codes_stride][8], out_lens = ceil(len / 320).
+int vx_encodec_encode(vx_ctx* c, const float* wav, int64_t wav_stride, const int32_t* lens, int32_t batch,
+                      int64_t* codes, int32_t codes_stride, int32_t* out_lens) {
+  if (!c || !wav || !lens || !codes || !out_lens) return VX_EINVAL;
+  if (!c->finalized || !c->has_encodec_enc) FAIL(VX_ESTATE, "EnCodec encoder weights not loaded");
+  if (batch <= 0) FAIL(VX_EINVAL, "bad batch");
+  HIPCHK(hipSetDevice(c->dev));
+  hipStream_t st = c->stream;
+  const int ratios[4] = {2, 4, 5, 8};
+  const long sample_cap = std::min<long>((long)c->cfg.max_new * 320, c->ec_frames_cap * 320);
+  for (int r0 = 0; r0 < batch; r0 += c->mbr) {
+    const int nb = std::min(c->mbr, batch - r0);
+    // stage lengths per sequence: L -> ceil(L/2) -> ceil(/4) -> ceil(/5) -> ceil(/8) = frames
+    std::vector<int> seq_off(nb), seq_len(nb), one_off, one_len;
+    std::vector<std::array<long, 5>> Ls(nb);
+    long F = 0;
+    int maxT = 0;
+    for (int i = 0; i < nb; ++i) {
+      const long L = lens[r0 + i];
+      if (L <= 0 || L > sample_cap || L > wav_stride) FAIL(VX_EINVAL, "row %d: bad length %ld (cap %ld samples)", r0 + i, L, sample_cap);
+      Ls[i][0] = L;
+      for (int s4 = 0; s4 < 4; ++s4) Ls[i][s4 + 1] = (Ls[i][s4] + ratios[s4] - 1) / ratios[s4];
+      const int T = (int)Ls[i][4];
+      if (T > codes_stride) FAIL(VX_EINVAL, "codes_stride too small");
+      seq_off[i] = (int)F; seq_len[i] = T; maxT = std::max(maxT, T);
+      F += T;
+      for (int s4 = 0; s4 < 4; ++s4) { one_off.push_back(0); one_len.push_back((int)Ls[i][s4]); }   // resblock im2col of stage s4
+    }
+    if (F > c->ec_frames_cap) FAIL(VX_EINVAL, "too many frames");
+    MetaBuilder mb(c);
+    const long o_off = mb.add(seq_off), o_len = mb.add(seq_len), o_1off = mb.add(one_off), o_1len = mb.add(one_len);
+    if (int e = upload_meta(c)) return e;
+    const int* d_off = mb.dev(o_off);
+    const int* d_len = mb.dev(o_len);
+    // ---- convolutional stack, one sequence at a time (prompts are few and long; the arena is reused) ----
+    for (int i = 0; i < nb; ++i) {
+      HIPCHK(hipMemcpyAsync(c->ec_audio, wav + (long)(r0 + i) * wav_stride, (size_t)Ls[i][0] * sizeof(float),
+                            hipMemcpyHostToDevice, st));
+      launch_enc_first_conv(c->ec_audio, Ls[i][0], W(c, "encodec.encoder.0.weight"), W(c, "encodec.encoder.0.bias"), c->ec_a, st);
+      int C = 32;
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int r = ratios[s4];
+        const long Lc = Ls[i][s4], n_out = Ls[i][s4 + 1];
+        const std::string pR = "encodec.encoder." + std::to_string(1 + 3 * s4), pD = "encodec.encoder." + std::to_string(3 + 3 * s4);
+        const int ldh = std::max(C / 2, 32);
+        // ResnetBlock: shortcut(x) + conv_k1(ELU(conv_k3(ELU(x))))
+        gemm(c, c->ec_a, C, W(c, pR + ".shortcut.weight"), C, W(c, pR + ".shortcut.bias"), nullptr, 0, nullptr, c->ec_sc, C, Lc, C,
+             C, ACT_NONE);
+        launch_im2col_seq(c->ec_a, C, 3, 0, 1, mb.dev(o_1off) + i * 4 + s4, mb.dev(o_1len) + i * 4 + s4, 1, c->ec_col, 3 * C, 1, Lc, st);
+        if (ldh != C / 2) HIPCHK(hipMemsetAsync(c->ec_h, 0, (size_t)Lc * ldh * sizeof(float), st));
+        gemm(c, c->ec_col, 3 * C, c->en_w1[s4], 3 * C, W(c, pR + ".block1.bias"), nullptr, 0, nullptr, c->ec_h, ldh, Lc, C / 2, 3 * C,
+             ACT_ELU);
+        gemm(c, c->ec_h, ldh, c->en_w3[s4], ldh, W(c, pR + ".block3.bias"), c->ec_sc, C, nullptr, c->ec_out, C, Lc, C, ldh, ACT_NONE);
+        // ELU + Conv1d(C, 2C, k = 2r, stride r), causal: left pad r, right pad to a whole frame (both reflect); the window
+        // of output frame t' is rows [t' r, (t' + 2) r) of the padded copy -> a GEMM with overlapping A rows (lda = r C)
+        const long rows = (n_out + 1) * r, extra = n_out * r - Lc;
+        const long max_pad = std::max<long>(r, extra);
+        const long Le = Lc <= max_pad ? Lc + (max_pad - Lc + 1) : Lc;         // EncodecConv1d._pad1d: short inputs are zero-extended
+        launch_enc_pad_elu(c->ec_out, Lc, Le, C, r, rows, c->ec_col, st);
+        float* dst = s4 < 3 ? c->ec_a : c->ec_x0 + (size_t)seq_off[i] * 512;
+        gemm(c, c->ec_col, r * C, c->en_wd[s4], 2 * r * C, W(c, pD + ".bias"), nullptr, 0, nullptr, dst, 2 * C, n_out, 2 * C, 2 * r * C,
+             ACT_NONE);
+        C *= 2;
+      }
+    }
+    // ---- 2-layer LSTM + skip on the packed frames (all sequences in lock-step, as in the decoder) ----
+    const float* lin = c->ec_x0;
+    for (int l = 0; l < 2; ++l) {
+      const std::string sfx = "_l" + std::to_string(l);
+      gemm(c, lin, 512, W(c, "encodec.encoder.13.lstm.weight_ih" + sfx), 512, c->en_lstm_b[l], nullptr, 0, nullptr, c->ec_xg, 2048, F,
+           2048, 512, ACT_NONE);
+      HIPCHK(hipMemsetAsync(c->ec_hp, 0, (size_t)MB * 512 * sizeof(float), st));
+      HIPCHK(hipMemsetAsync(c->ec_c, 0, (size_t)MB * 512 * sizeof(float), st));
+      float* yout = l == 0 ? c->ec_y1 : c->ec_y2;
+      for (int t = 0; t < maxT; ++t) {
+        launch_skinny_gemm(c->en_whh_p[l], c->ec_hp, c->ec_pg, 2048, 512, 2, nullptr, st);
+        launch_lstm_cell(c->ec_pg, 2, c->ec_xg, d_off, d_len, t, c->ec_c, c->ec_hp, yout, l == 1 ? c->ec_x0 : nullptr, nb, st);
+      }
+      lin = yout;
+    }
+    // ---- ELU + Conv1d(512, 128, k7) -> embeddings [F][128] ----
+    launch_im2col_seq(c->ec_y2, 512, 7, 0, 1, d_off, d_len, 1, c->ec_col, 3584, nb, maxT, st);
+    gemm(c, c->ec_col, 3584, c->en_w15, 3584, W(c, "encodec.encoder.15.bias"), nullptr, 0, nullptr, c->ec_e0, 128, F, 128, 3584, ACT_NONE);
+    // ---- residual VQ, 8 codebooks: scores = r . E_q^T, argmax of -(|r|^2 - 2 s + |e|^2), r -= E_q[code] ----
+    for (int q = 0; q < N_Q; ++q) {
+      const float* Eq = c->ec_codebook + (size_t)q * 1024 * 128;
+      gemm(c, c->ec_e0, 128, Eq, 128, nullptr, nullptr, 0, nullptr, c->en_scores, 1024, F, 1024, 128, ACT_NONE);
+      launch_rvq_select(c->ec_e0, c->en_scores, c->en_e2 + (size_t)q * 1024, Eq, c->en_codes, q, F, st);
+    }
+    std::vector<long long> hc((size_t)F * 8);
+    HIPCHK(hipMemcpyAsync(hc.data(), c->en_codes, hc.size() * sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    for (int i = 0; i < nb; ++i) {
+      out_lens[r0 + i] = seq_len[i];
+      for (int t = 0; t < seq_len[i]; ++t)
+        for (int q = 0; q < N_Q; ++q)
+          codes[((long)(r0 + i) * codes_stride + t) * N_Q + q] = (int64_t)hc[((size_t)seq_off[i] + t) * 8 + q];
+    }
   }
   return VX_OK;
 }

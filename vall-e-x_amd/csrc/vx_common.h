@@ -160,6 +160,11 @@ void launch_final_conv(const float* x, const float* w, const float* bias, const 
                        float* audio, long audio_stride, int batch, long max_rows, hipStream_t s);
 
 // ---- Vocos head (vocos.hip) --------------------------------------------------------------------
+// encoder side (encodec.hip): first Conv1d(1,32,k7); ELU + causal reflect padding of a strided conv; one residual-VQ step
+void launch_enc_first_conv(const float* wav, long L, const float* w, const float* bias, float* out, hipStream_t s);
+void launch_enc_pad_elu(const float* x, long L, long Le, int C, int left, long rows, float* out, hipStream_t s);
+void launch_rvq_select(float* resid, const float* scores, const float* e2, const float* codebook, long long* codes, int q,
+                       long rows, hipStream_t s);
 void launch_codebook_sum(const int* codes, const float* codebook, float* feat, int rows, hipStream_t s);
 void launch_im2col7(const float* x, int C, const int* row_t, const int* row_len, float* out, int rows, hipStream_t s);
 void launch_dwconv7(const float* x, const float* w, const float* bias, const int* row_t, const int* row_len,

@@ -1,8 +1,9 @@
-"""Mirror of the decode half of the reference's `data/tokenizer.py` (`AudioTokenizer`, :63-96) on MI355X.
+"""Mirror of the reference's `data/tokenizer.py` (`AudioTokenizer`, :63-96) on MI355X.
 
 `AudioTokenizer.decode(frames)` = `EncodecModel.encodec_model_24khz().decode(frames)` -- the EnCodec SEANet decoder, the
-reference's legacy vocoder beside Vocos (README.md:29-30).  The arithmetic lives in the pip package `encodec`; here it runs
-in libvallex_hip.so (`vx_encodec_decode`).  `encode` (prompt enrolment) is not on the inference hot path and is not built.
+reference's legacy vocoder beside Vocos (README.md:29-30); `AudioTokenizer.encode(wav)` = `.encode(wav)` at 6 kbps -- the
+SEANet encoder + residual VQ used for prompt enrolment (data/tokenizer.py:92-111).  The arithmetic lives in the pip package
+`encodec`; here it runs in libvallex_hip.so (`vx_encodec_decode`, `vx_encodec_encode`).
 
 Weights: pass the `encodec` package's state-dict (`decoder.model.N...`, weight_g / weight_v or plain weight after
 `remove_weight_norm`, data/tokenizer.py:33-60), the `transformers` port's (`decoder.layers.N...parametrizations...`), or
@@ -37,8 +38,9 @@ _SUB = {"block.1": "block1", "block.3": "block3", "block1": "block1", "block3": 
 
 
 def canonical_encodec_state_dict(sd: Dict[str, Any]) -> Dict[str, np.ndarray]:
-    """-> {'quantizer.{q}.embed', 'decoder.{i}.weight|bias', 'decoder.{i}.block1|block3|shortcut.weight|bias',
-    'decoder.1.lstm.*'} with weight-norm folded, for the first 8 codebooks and the decoder only."""
+    """-> {'quantizer.{q}.embed', '{decoder|encoder}.{i}.weight|bias', '....{i}.block1|block3|shortcut.weight|bias',
+    'decoder.1.lstm.*', 'encoder.13.lstm.*'} with weight-norm folded, for the first 8 codebooks, the SEANet decoder and
+    (when present) the SEANet encoder."""
     out: Dict[str, np.ndarray] = {}
     pend: Dict[str, Dict[str, np.ndarray]] = {}
     for k, v in sd.items():
@@ -48,12 +50,12 @@ def canonical_encodec_state_dict(sd: Dict[str, Any]) -> Dict[str, np.ndarray]:
             if int(m.group(1)) < 8:
                 out[f"quantizer.{int(m.group(1))}.embed"] = _np(v)
             continue
-        m = re.match(r"decoder\.(?:model\.|layers\.)?(\d+)\.(.*)$", k)
+        m = re.match(r"(decoder|encoder)\.(?:model\.|layers\.)?(\d+)\.(.*)$", k)
         if not m:
             continue
-        i, rest = int(m.group(1)), m.group(2)
+        side, i, rest = m.group(1), int(m.group(2)), m.group(3)
         if rest.startswith("lstm."):
-            out[f"decoder.{i}.{rest}"] = _np(v)
+            out[f"{side}.{i}.{rest}"] = _np(v)
             continue
         sub = ""
         for a, b in _SUB.items():
@@ -61,7 +63,7 @@ def canonical_encodec_state_dict(sd: Dict[str, Any]) -> Dict[str, np.ndarray]:
                 sub, rest = b + ".", rest[len(a) + 1:]
                 break
         rest = re.sub(r"^(conv\.conv\.|convtr\.convtr\.|conv\.)", "", rest)
-        base = f"decoder.{i}.{sub}"
+        base = f"{side}.{i}.{sub}"
         if rest in ("weight", "bias"):
             out[base + rest] = _np(v)
         elif rest in ("weight_g", "parametrizations.weight.original0"):
@@ -69,7 +71,8 @@ def canonical_encodec_state_dict(sd: Dict[str, Any]) -> Dict[str, np.ndarray]:
         elif rest in ("weight_v", "parametrizations.weight.original1"):
             pend.setdefault(base, {})["v"] = _np(v)
     for base, gv in pend.items():
-        out[base + "weight"] = _fold(gv["g"], gv["v"])
+        if "g" in gv and "v" in gv:                      # a lone half (stray / partial dict) is ignored
+            out[base + "weight"] = _fold(gv["g"], gv["v"])
     return out
 
 
@@ -88,7 +91,17 @@ class AudioTokenizer:
         return self._device
 
     def encode(self, wav):
-        raise NotImplementedError("EnCodec encoder / prompt enrolment is outside the inference hot path (SURVEY.md §8f rank 3)")
+        """wav (B, 1, L) or (B, L) mono 24 kHz fp32 -> [(codes (B, 8, T) int64, None)] like `codec.encode` at 6 kbps
+        (data/tokenizer.py:92-93); T = ceil(L / 320).  All rows of one call have the same length, as a tensor does."""
+        w = wav.detach().cpu().numpy() if torch is not None and isinstance(wav, torch.Tensor) else np.asarray(wav)
+        w = np.asarray(w, np.float32)
+        if w.ndim == 3:
+            assert w.shape[1] == 1, w.shape              # mono (convert_audio(..., target_channels=1), data/tokenizer.py:103)
+            w = w[:, 0]
+        assert w.ndim == 2, w.shape
+        codes = self._m.engine.encodec_encode([w[i] for i in range(w.shape[0])])
+        out = np.ascontiguousarray(np.transpose(np.stack(codes), (0, 2, 1))).astype(np.int64)      # (B, 8, T)
+        return [(torch.from_numpy(out) if torch is not None else out, None)]
 
     def decode(self, frames):
         """frames: [(codes (B, 8, T), scale=None)] as produced by encodec; returns (B, 1, 320*T)."""

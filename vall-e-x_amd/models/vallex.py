@@ -139,7 +139,8 @@ class VALLE:
 
     def load_encodec_state_dict(self, state_dict):
         """Weights of `EncodecModel.encodec_model_24khz()` (data/tokenizer.py:71-73): encodec-package, transformers-port or
-        canonical key names; only the RVQ codebooks and the SEANet decoder are used."""
+        canonical key names.  The RVQ codebooks and the SEANet decoder are required; if the SEANet encoder is in the dict too,
+        `AudioTokenizer.encode` (prompt enrolment) is available as well."""
         from ..data.tokenizer import canonical_encodec_state_dict
         self._encodec_sd = canonical_encodec_state_dict(state_dict)
         self._engine = None
