@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP engine (through the C ABI) vs the committed outputs of the live reference
 (tests/golden) and vs the CPU oracle on the same seeded inputs.  Bit-exact token ids; logits/activations within
 fp32-summation-order tolerance (written at each assert)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -256,8 +258,9 @@ def test_engine_rejects_bad_arguments():
                           temperature=0.0)
 
 
-@pytest.mark.xfail(strict=False, reason="written after this round's GPU budget was spent; the oracle side is pinned to the live "
-                                        "reference on CPU (test_oracle_golden.py), the first hardware run is the round-end one")
+@pytest.mark.skipif(os.environ.get("VX_RUN_UNVALIDATED") != "1",
+                    reason="written after this round's GPU budget was spent (oracle side pinned to the live reference on CPU, "
+                           "test_oracle_golden.py); set VX_RUN_UNVALIDATED=1 for its first hardware run")
 @pytest.mark.parametrize("name", sorted(CONTINUAL_CASES))
 def test_continual_matches_reference(name):
     """`VALLE.continual` (models/vallex.py:688-787) through vx_nar with language id -1 (= no language embedding):
