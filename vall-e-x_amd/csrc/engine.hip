@@ -609,6 +609,18 @@ int pack(vx_ctx* c, const float* Wt, int N, int K, int Npad, float** out) {
   return VX_OK;
 }
 
+// Kernel-development aid (VX_BENCH_CLOCK=1 in vx_bench_gemm): one wave that sits next to the kernel under test for `ref_ticks` of
+// the constant 100 MHz counter and reports how many shader-clock ticks (s_memtime) went by -> the clock the chip actually
+// holds under that load.  Bounded by the real-time counter, so it always terminates.
+__global__ void clock_probe_kernel(unsigned long long* out, unsigned long long ref_ticks) {
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_readcyclecounter();
+  while (__builtin_amdgcn_s_memrealtime() - r0 < ref_ticks) __builtin_amdgcn_s_sleep(16);
+  if (threadIdx.x == 0) {
+    out[0] = __builtin_readcyclecounter() - c0;
+    out[1] = __builtin_amdgcn_s_memrealtime() - r0;
+  }
+}
+
 }  // namespace
 
 // =================================================================================================================
@@ -1713,11 +1725,22 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
     else launch_gemm_bf16x3_probe(gx, kernel - 10, c->stream);      // 11 / 12 / 13: timing probes
   };
   run();
+  // VX_BENCH_CLOCK=1: sample the shader clock on a second stream while the timed launches run (power / clock ceiling check)
+  const char* want_clock = getenv("VX_BENCH_CLOCK");
+  hipStream_t s2 = nullptr;
+  unsigned long long* d_clk = nullptr;
+  if (want_clock && want_clock[0] == '1') {
+    TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    TRY(hipMalloc((void**)&d_clk, 16));
+    TRY(hipStreamSynchronize(c->stream));
+  }
   hipEvent_t e0, e1;
   TRY(hipEventCreate(&e0));
   TRY(hipEventCreate(&e1));
   TRY(hipEventRecord(e0, c->stream));
-  for (int r = 0; r < reps; ++r) run();
+  run();                                                           // the probe starts once the device is busy
+  if (s2) hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, s2, d_clk, 100ull * 2000ull);   // 2 ms at 100 MHz
+  for (int r = 1; r < reps; ++r) run();
   TRY(hipEventRecord(e1, c->stream));
   TRY(hipEventSynchronize(e1));
   float ms = 0;
@@ -1725,6 +1748,15 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   *avg_us = (double)ms * 1e3 / reps;
+  if (s2) {
+    unsigned long long hclk[2] = {0, 0};
+    TRY(hipStreamSynchronize(s2));
+    TRY(hipMemcpy(hclk, d_clk, 16, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[vx_bench_gemm] kernel %d M=%d N=%d K=%d: shader clock while running = %.0f MHz (%llu ticks in %.3f ms)\n", kernel,
+            M, N, K, hclk[1] ? (double)hclk[0] / ((double)hclk[1] / 100.0) : 0.0, hclk[0], (double)hclk[1] / 1e5);
+    (void)hipFree(d_clk);
+    (void)hipStreamDestroy(s2);
+  }
   const int rows = std::min(M, 256);
   std::vector<float> h0((size_t)rows * N), h1((size_t)rows * N);
   TRY(hipMemcpy(h0.data(), C0, h0.size() * 4, hipMemcpyDeviceToHost));
