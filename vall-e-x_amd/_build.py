@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libvallex_hip.so")
-SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "gemm_bf16x3_dma.hip", "gemm_bf16x3_ring.hip", "gemm_bf16x3_pipe.hip", "rows.hip", "attn_full.hip", "attn_full_x3.hip", "decode.hip", "vocos.hip", "encodec.hip", "engine.hip"]
+SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "gemm_bf16x3_dma.hip", "gemm_bf16x3_ring.hip", "gemm_bf16x3_pipe.hip", "gemm_f16x2_dma.hip", "rows.hip", "attn_full.hip", "attn_full_x3.hip", "decode.hip", "vocos.hip", "encodec.hip", "engine.hip"]
 HEADERS = ["vx_common.h", os.path.join("..", "..", "include", "vallex_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 

@@ -1672,7 +1672,7 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
 }
 
 // Stand-alone GEMM micro-benchmark on scratch buffers (kernel development aid; never on the product path):
-// kernel 0 = gemm_f32, 1 = gemm_bf16x3, 2 = gemm_bf16x3_dma, 3 = gemm_bf16x3_ring, 4 = ring4, 5 = pipe;
+// kernel 0 = gemm_f32, 1 = gemm_bf16x3, 2 = gemm_bf16x3_dma, 3 = gemm_bf16x3_ring, 4 = ring4, 5 = pipe, 6 = f16x2 (experiment);
 // 11-13 / 21-24 = timing probes of the register-staged / DMA kernel (results meaningless).  Reports the average launch time and the max abs
 // difference of the first 256 output rows against the fp32-MFMA kernel.
 int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, int32_t reps, double* avg_us,
@@ -1702,7 +1702,10 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
   GemmArgs g0{};
   g0.A = A; g0.lda = K; g0.W = Wt; g0.ldw = K; g0.C = C0; g0.ldc = N; g0.M = M; g0.N = N; g0.K = K; g0.act = ACT_NONE;
   launch_gemm_f32(g0, c->stream);
-  if (kernel == 3 || kernel == 4 || kernel == 5) {                              // k-step-major planes for the ring kernels
+  if (kernel == 6) {                                             // fp16 head / scaled tail planes for the f16x2 experiment
+    launch_split2h(A, K, M, K, A3, (long)M * K, c->stream);
+    launch_split2h(Wt, K, N, K, W3, (long)N * K, c->stream);
+  } else if (kernel == 3 || kernel == 4 || kernel == 5) {                              // k-step-major planes for the ring kernels
     launch_split3_k16(A, K, M, K, nullptr, A3, (long)M * K, c->stream);
     launch_split3_k16(Wt, K, N, K, nullptr, W3, (long)N * K, c->stream);
   } else {
@@ -1721,6 +1724,7 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
     else if (kernel == 3) launch_gemm_bf16x3_ring(gx, c->stream);
     else if (kernel == 4) launch_gemm_bf16x3_ring4(gx, c->stream);
     else if (kernel == 5) launch_gemm_bf16x3_pipe(gx, c->stream);
+    else if (kernel == 6) launch_gemm_f16x2_dma(gx, c->stream);
     else if (kernel >= 21) launch_gemm_bf16x3_dma_probe(gx, kernel - 20, c->stream);   // 21-24: probes of the DMA kernel
     else launch_gemm_bf16x3_probe(gx, kernel - 10, c->stream);      // 11 / 12 / 13: timing probes
   };
