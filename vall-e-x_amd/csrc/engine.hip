@@ -71,6 +71,7 @@ struct vx_ctx {
 
   // bf16x3 GEMM path (default) for the transformer projections of prefill / NAR; VX_GEMM_F32=1 keeps the fp32 MFMA
   bool x3 = true;
+  bool gemm_h2 = false;                       // VX_GEMM_H2=1: EXPERIMENT gemm_f16x2_dma.hip (fp16 head + scaled tail, 3 MFMAs per block, ~2^-22)
   bool gemm_pipe = false;                     // VX_GEMM_PIPE=1: gemm_bf16x3_pipe.hip (4-stage ring + fragment prefetch across the rendezvous), k-step-major planes
   bool gemm_ring = false;                     // VX_GEMM_RING=1: 256x256 three-stage ring kernel (gemm_bf16x3_ring.hip, k-step-major planes).
                                               // +4 % on the isolated GEMM, no end-to-end gain over the DMA kernel; kept selectable
@@ -247,18 +248,20 @@ void proj(vx_ctx* c, const float* A, int lda, const float* Wf, const unsigned sh
     return;
   }
   const bool k16 = c->gemm_ring || c->gemm_pipe;                 // kernels on k-step-major planes
-  if (k16 && M < 1024) {                                // the ring kernel's tiles are 256 rows: short row sets
+  if ((k16 || c->gemm_h2) && M < 1024) {                                // the ring kernel's tiles are 256 rows: short row sets
     gemm(c, A, lda, Wf, K, bias, resid, ldr, nullptr, C, ldc, M, N, K, act, gather);   // take the exact fp32 kernel
     return;
   }
-  if (k16) launch_split3_k16(A, lda, M, K, gather, c->fa3, (long)M * K, c->stream);
+  if (c->gemm_h2) launch_split2h(A, lda, M, K, gather, c->fa3, (long)M * K, c->stream);
+  else if (k16) launch_split3_k16(A, lda, M, K, gather, c->fa3, (long)M * K, c->stream);
   else launch_split3(A, lda, M, K, gather, c->fa3, (long)M * K, c->stream);
   GemmX3Args g{};
   g.A = c->fa3; g.a_plane = (long)M * K; g.W = W3; g.w_plane = (long)N * K; g.bias = bias; g.resid = resid; g.ldr = ldr;
   g.colscale = nullptr; g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.act = act;
   ProfScope ps(c, 2);
   if (c->prof_on) c->prof[2].bytes += 2.0 * (double)M * N * K;
-  if (c->gemm_pipe) launch_gemm_bf16x3_pipe(g, c->stream);
+  if (c->gemm_h2) launch_gemm_f16x2_dma(g, c->stream);
+  else if (c->gemm_pipe) launch_gemm_bf16x3_pipe(g, c->stream);
   else if (c->gemm_ring) launch_gemm_bf16x3_ring(g, c->stream);
   else if (c->gemm_dma && M >= 1024) launch_gemm_bf16x3_dma(g, c->stream);   // 256-row tiles: not for short row sets
   else launch_gemm_bf16x3(g, c->stream);
@@ -821,10 +824,12 @@ int vx_finalize_weights(vx_ctx* c) {
   if (const char* ev = getenv("VX_GEMM_DMA")) c->gemm_dma = !(ev[0] == '0');
   if (const char* ev = getenv("VX_GEMM_RING")) c->gemm_ring = (ev[0] == '1');
   if (const char* ev = getenv("VX_GEMM_PIPE")) c->gemm_pipe = (ev[0] == '1');
+  if (const char* ev = getenv("VX_GEMM_H2")) c->gemm_h2 = (ev[0] == '1');
   if (c->x3) {
     auto split_w = [&](const float* Wt, int N, int K, unsigned short** out) -> int {
       if (int e2 = dev_alloc(c, out, (size_t)3 * N * K, false)) return e2;
-      if (c->gemm_ring || c->gemm_pipe) launch_split3_k16(Wt, K, N, K, nullptr, *out, (long)N * K, c->stream);
+      if (c->gemm_h2) launch_split2h(Wt, K, N, K, nullptr, *out, (long)N * K, c->stream);
+      else if (c->gemm_ring || c->gemm_pipe) launch_split3_k16(Wt, K, N, K, nullptr, *out, (long)N * K, c->stream);
       else launch_split3(Wt, K, N, K, nullptr, *out, (long)N * K, c->stream);
       return VX_OK;
     };
@@ -1703,8 +1708,8 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
   g0.A = A; g0.lda = K; g0.W = Wt; g0.ldw = K; g0.C = C0; g0.ldc = N; g0.M = M; g0.N = N; g0.K = K; g0.act = ACT_NONE;
   launch_gemm_f32(g0, c->stream);
   if (kernel == 6) {                                             // fp16 head / scaled tail planes for the f16x2 experiment
-    launch_split2h(A, K, M, K, A3, (long)M * K, c->stream);
-    launch_split2h(Wt, K, N, K, W3, (long)N * K, c->stream);
+    launch_split2h(A, K, M, K, nullptr, A3, (long)M * K, c->stream);
+    launch_split2h(Wt, K, N, K, nullptr, W3, (long)N * K, c->stream);
   } else if (kernel == 3 || kernel == 4 || kernel == 5) {                              // k-step-major planes for the ring kernels
     launch_split3_k16(A, K, M, K, nullptr, A3, (long)M * K, c->stream);
     launch_split3_k16(Wt, K, N, K, nullptr, W3, (long)N * K, c->stream);

@@ -1,4 +1,4 @@
-// EXPERIMENT (bench-only, kernel id 6 of vx_bench_gemm; not on the product path): "f16x2" GEMM -- every fp32 operand is split
+// EXPERIMENT (kernel id 6 of vx_bench_gemm; on the model path only with VX_GEMM_H2=1, never by default): "f16x2" GEMM -- every fp32 operand is split
 // into an fp16 head and an fp16 tail scaled by 2^11,
 //     x = h + t / 2048,   h = fp16(x),   t = fp16((x - h) * 2048)          (22 significant bits, exact scaling)
 // and   a.b ~= ha.hb + (ha.tb + ta.hb) / 2048      with the two groups in separate fp32 accumulators,
@@ -32,15 +32,18 @@ typedef void __attribute__((address_space(3)))* lptr_t;
 
 }  // namespace
 
-// x[rows][K] fp32 -> planes[p][K/32][rows][32] fp16 (K-tile-major like split3_kernel), p = 0 head, 1 tail * 2048
+// x[rows][K] fp32 (row r read at gather ? gather[r] : r) -> planes[p][K/32][rows][32] fp16 (K-tile-major like split3_kernel),
+// p = 0 head, 1 tail * 2048
 __global__ __launch_bounds__(256) void split2h_kernel(const float* __restrict__ x, int ldx, long rows, int K,
+                                                      const int* __restrict__ gather,
                                                       unsigned short* __restrict__ planes, long plane_stride) {
   const long total = (long)(K / 32) * rows * 4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int ch = (int)(i & 3);
     const long rr = i >> 2;
     const long kt = rr / rows, r = rr - kt * rows;
-    const float* xp = x + r * ldx + kt * 32 + ch * 8;
+    const long src = gather ? gather[r] : r;
+    const float* xp = x + src * ldx + kt * 32 + ch * 8;
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(xp);
     const f32x4 v1 = *reinterpret_cast<const f32x4*>(xp + 4);
     const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -56,11 +59,12 @@ __global__ __launch_bounds__(256) void split2h_kernel(const float* __restrict__ 
   }
 }
 
-void launch_split2h(const float* x, int ldx, long rows, int K, unsigned short* planes, long plane_stride, hipStream_t s) {
+void launch_split2h(const float* x, int ldx, long rows, int K, const int* gather, unsigned short* planes, long plane_stride,
+                    hipStream_t s) {
   if (rows <= 0) return;
   const long total = rows * (K / 8);
   hipLaunchKernelGGL(split2h_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, x, ldx, rows, K,
-                     planes, plane_stride);
+                     gather, planes, plane_stride);
 }
 
 __global__ __launch_bounds__(512, 1) void gemm_f16x2_dma_kernel(GemmX3Args g) {

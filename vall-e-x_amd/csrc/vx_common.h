@@ -57,9 +57,10 @@ void launch_gemm_bf16x3_dma_probe(const GemmX3Args& g, int variant, hipStream_t 
 void launch_gemm_bf16x3_ring(const GemmX3Args& g, hipStream_t s);
 void launch_gemm_bf16x3_ring4(const GemmX3Args& g, hipStream_t s);
 void launch_gemm_bf16x3_pipe(const GemmX3Args& g, hipStream_t s);
-// EXPERIMENT (bench only): fp16 head + scaled fp16 tail, three f16 MFMAs per block (gemm_f16x2_dma.hip); planes [2][K/32][rows][32]
+// EXPERIMENT (bench kernel 6; model path only under VX_GEMM_H2=1): fp16 head + scaled fp16 tail, three f16 MFMAs per block (gemm_f16x2_dma.hip); planes [2][K/32][rows][32]
 void launch_gemm_f16x2_dma(const GemmX3Args& g, hipStream_t s);
-void launch_split2h(const float* x, int ldx, long rows, int K, unsigned short* planes, long plane_stride, hipStream_t s);    // gemm_bf16x3_pipe.hip: 4-stage ring + fragment prefetch   // 4 waves x (128 x 128)
+void launch_split2h(const float* x, int ldx, long rows, int K, const int* gather, unsigned short* planes, long plane_stride,
+                    hipStream_t s);    // gemm_bf16x3_pipe.hip: 4-stage ring + fragment prefetch   // 4 waves x (128 x 128)
 void launch_split3_k16(const float* x, int ldx, long rows, int K, const int* gather, unsigned short* planes,
                        long plane_stride, hipStream_t s);   // gemm_bf16x3_dma.hip: async LDS fill, 256x128 tile   // timing probes (tools/gemm_bench.py)
 void launch_split3(const float* x, int ldx, long rows, int K, const int* gather, unsigned short* planes,
