@@ -63,6 +63,15 @@ CASES = {
                           top_k=1, force_eos_at=24, useed=None),
 }
 
+# "sharp" attention (attn_gain 3: score std ~4.5 instead of ~0.5): a test bed that reacts to K/V and to the score arithmetic,
+# which the default random init (nearly uniform softmax) does not.  Kept apart from CASES: the GPU parity suite iterates CASES.
+SHARP_CASES = {
+    "nl2_sharp_greedy": dict(num_layers=2, seed=8, eos_gain=1.0, attn_gain=3.0, preset="librispeech_1", n_text=14, lang="en",
+                             top_k=1, force_eos_at=48, useed=None),
+    "nl2_sharp_topk10": dict(num_layers=2, seed=9, eos_gain=1.0, attn_gain=3.0, preset="cafe", n_text=12, lang="ja",
+                             top_k=10, force_eos_at=40, useed=555),
+}
+
 # VALLE.continual (models/vallex.py:688-787): text ids + a full (T, 8) code matrix; NAR stages only
 CONTINUAL_CASES = {
     "nl2_continual": dict(num_layers=2, seed=6, eos_gain=1.0, n_text=14, frames=61),          # prefix_len = 30
@@ -100,7 +109,7 @@ def run_reference(c):
 
     m = VALLE(1024, 16, c["num_layers"], norm_first=True, add_prenet=False, prefix_mode=1,
               share_embedding=True, nar_scale_factor=1.0, prepend_bos=True, num_quantizers=8).eval()
-    sd = synth.vallex_state_dict(c["num_layers"], c["seed"], c["eos_gain"])
+    sd = synth.vallex_state_dict(c["num_layers"], c["seed"], c["eos_gain"], c.get("attn_gain", 1.0))
     missing = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     a, t, text, pl, langs = case_inputs(c)
@@ -182,7 +191,7 @@ def main(only=None):
         out = run_reference_continual(c)
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
         print(name, out["codes"].shape, out["codes"][0, :4, 1], flush=True)
-    for name, c in CASES.items():
+    for name, c in list(CASES.items()) + list(SHARP_CASES.items()):
         if only and name not in only:
             continue
         out = run_reference(c)

@@ -50,12 +50,17 @@ def _normal(rng, shape, std=1.0):
     return (rng.standard_normal(size=shape) * std).astype(np.float32)
 
 
-def vallex_state_dict(num_layers: int = 12, seed: int = 0, eos_gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+def vallex_state_dict(num_layers: int = 12, seed: int = 0, eos_gain: float = 1.0,
+                      attn_gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
     """The 374-key (for 12 layers) fp32 state-dict, key order = reference order.
 
     eos_gain > 1 scales the EOS row of ar_predict_layer so greedy decoding
     terminates naturally (random weights otherwise always run to the 16*S cap,
     SURVEY.md §8c).
+    attn_gain > 1 scales the q and k rows of every in_proj (weights and biases): with the default init the attention
+    scores have std ~0.5, i.e. a nearly uniform softmax that hides errors in K/V and in the score arithmetic; gain 3
+    gives scores of std ~4.5 and peaky, trained-looking attention ("sharp" golden cases).  The RNG stream, and with it
+    every other tensor, is the same for any gain.
     """
     rng = np.random.default_rng(seed)
     d, f = D_MODEL, D_FF
@@ -70,6 +75,9 @@ def vallex_state_dict(num_layers: int = 12, seed: int = 0, eos_gain: float = 1.0
         xav = math.sqrt(6.0 / (d + 3 * d))
         sd[prefix + "self_attn.in_proj_weight"] = _uniform(rng, (3 * d, d), xav)
         sd[prefix + "self_attn.in_proj_bias"] = _uniform(rng, (3 * d,), 0.02)
+        if attn_gain != 1.0:
+            sd[prefix + "self_attn.in_proj_weight"][: 2 * d] *= np.float32(attn_gain)
+            sd[prefix + "self_attn.in_proj_bias"][: 2 * d] *= np.float32(attn_gain)
         sd[prefix + "self_attn.out_proj.weight"] = _uniform(rng, (d, d), 1 / math.sqrt(d))
         sd[prefix + "self_attn.out_proj.bias"] = _uniform(rng, (d,), 0.02)
         sd[prefix + "linear1.weight"] = _uniform(rng, (f, d), 1 / math.sqrt(d))

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import synth
-from oracle.make_golden import CASES, CONTINUAL_CASES, continual_inputs
+from oracle.make_golden import CASES, CONTINUAL_CASES, SHARP_CASES, case_inputs, continual_inputs
 from oracle.vallex_oracle import VallexOracle, VocosOracle
 from tests._util import case_row, get_model, golden
 
@@ -269,5 +269,20 @@ def test_continual_matches_reference(name):
     m = get_model(c["num_layers"], c["seed"], c["eos_gain"])
     text, y = continual_inputs(c)
     out = m.continual(text, np.array([text.shape[-1]]), y)
+    out = out.numpy() if hasattr(out, "numpy") else out
+    np.testing.assert_array_equal(out, golden(name)["codes"])
+
+
+@pytest.mark.skipif(os.environ.get("VX_RUN_UNVALIDATED") != "1",
+                    reason="goldens added after this round's GPU budget was spent; set VX_RUN_UNVALIDATED=1 for the first hardware run")
+@pytest.mark.parametrize("name", sorted(SHARP_CASES))
+def test_infer_matches_reference_tokens_sharp_attention(name):
+    """The attn_gain-3 goldens (peaky attention: sensitive to K/V precision and score arithmetic) through the C ABI."""
+    c = SHARP_CASES[name]
+    m = get_model(c["num_layers"], c["seed"], c["eos_gain"], attn_gain=c["attn_gain"])
+    a, t, text, pl, langs = case_inputs(c)
+    us = None if c["useed"] is None else synth.uniforms(4096, 1, c["useed"])[:, 0]
+    out = m.inference(text, np.array([text.shape[-1]]), a, t.shape[-1], top_k=c["top_k"], prompt_language=pl, text_language=langs,
+                      uniforms=us, force_eos_at=c["force_eos_at"])
     out = out.numpy() if hasattr(out, "numpy") else out
     np.testing.assert_array_equal(out, golden(name)["codes"])

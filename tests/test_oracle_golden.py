@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import synth
-from oracle.make_golden import CASES, CONTINUAL_CASES, GOLD, case_inputs, continual_inputs
+from oracle.make_golden import CASES, CONTINUAL_CASES, GOLD, SHARP_CASES, case_inputs, continual_inputs
 from oracle.vallex_oracle import VallexOracle
 
 FAST = [n for n in CASES if n.startswith("nl2_")]
@@ -67,3 +67,16 @@ def test_oracle_continual_matches_reference(name):
     assert out.shape == g.shape == (1, y.shape[1] - prefix_len, 8)
     np.testing.assert_array_equal(out, g)
     np.testing.assert_array_equal(out[0, :, 0], y[0, prefix_len:, 0])      # first codebook is passed through
+
+
+@pytest.mark.parametrize("name", sorted(SHARP_CASES))
+def test_oracle_matches_reference_tokens_sharp_attention(name):
+    """attn_gain 3 weights (peaky, trained-looking attention): this test bed reacts to K/V precision and to the score
+    arithmetic, which the default random init does not.  Golden = the live reference."""
+    c = SHARP_CASES[name]
+    orc = VallexOracle(synth.vallex_state_dict(c["num_layers"], c["seed"], c["eos_gain"], c["attn_gain"]), c["num_layers"])
+    a, t, text, pl, langs = case_inputs(c)
+    us = None if c["useed"] is None else synth.uniforms(4096, 1, c["useed"])[:, 0]
+    codes = orc.inference(text, np.array([text.shape[-1]]), a, t.shape[-1], top_k=c["top_k"], prompt_language=pl,
+                          text_language=langs, uniforms=us, force_eos_at=c["force_eos_at"])
+    np.testing.assert_array_equal(codes, np.load(os.path.join(GOLD, name + ".npz"))["codes"])
