@@ -29,9 +29,16 @@ extern "C" {
 
 typedef struct vx_ctx vx_ctx;
 
+/* ABI guard.  Every descriptor struct starts with `struct_size` = sizeof(that struct) as the CALLER compiled it; the library
+ * rejects a mismatch with VX_EINVAL instead of reading past the end of a shorter (older) struct.  vx_abi_version() returns
+ * VX_ABI_VERSION of the library that was actually loaded, so a binding can check it before the first call. */
+#define VX_ABI_VERSION 2
+int32_t vx_abi_version(void);
+
 /* Model/arena geometry.  d_model=1024, 16 heads, FFN 4096, 8 codebooks are fixed by the kernels
  * (macros.py:1-6, utils/generation.py:67-78); the layer count is configurable so tests can run reduced stacks. */
 typedef struct vx_config {
+  uint32_t struct_size;    /* = sizeof(vx_config) */
   int32_t num_layers;      /* 12 for the shipped checkpoint */
   int32_t max_batch;       /* rows per vx_infer call; AR runs in micro-batches of <= 32 rows */
   int32_t max_text;        /* max text ids per row (prompt text + text), S */
@@ -62,6 +69,7 @@ int vx_finalize_weights(vx_ctx* ctx);
 /* ---- batch descriptor -------------------------------------------------------------------------------------
  * One row = one utterance = one reference `VALLE.inference(x, x_lens, y, enroll_x_lens, ...)` call. */
 typedef struct vx_batch {
+  uint32_t struct_size;         /* = sizeof(vx_batch) */
   int32_t batch;
   const int32_t* text_ids;      /* [batch][text_stride]   x: prompt text ids ++ text ids (utils/generation.py:133) */
   const int32_t* text_lang;     /* [batch][text_stride]   per-token MODEL language id en0/zh1/ja2 (models/vallex.py:439-443,
@@ -76,6 +84,7 @@ typedef struct vx_batch {
 
 /* topk_sampling arguments (models/vallex.py:836-853) + reproducibility hooks */
 typedef struct vx_sampling {
+  uint32_t struct_size;         /* = sizeof(vx_sampling) */
   int32_t top_k;                /* <= 0: no filtering (API default -100); 1: greedy */
   float temperature;            /* > 0 */
   const float* uniforms;        /* optional [uniforms_steps][batch] in [0,1): inverse-CDF draws replacing

@@ -72,6 +72,27 @@ SHARP_CASES = {
                              top_k=10, force_eos_at=40, useed=555),
 }
 
+# BASELINE C1/C2/C3 shape at FULL length: 12 layers, preset prompt + 100 phoneme ids, EOS forced at
+# 600 frames (8.0 s) => Ltot = S + Tp + 600 ~ 983 for librispeech_1.  Weights = the bench weights (seed 0, eos_gain 0: the EOS
+# logit is exactly 0, never the arg-max and never inside the top-10, so no run ends early).  All six share ONE weight set so
+# the GPU test can put several rows in one `inference_batch` call (packed rows >= 1024 => the DMA bf16x3 GEMM and attn_full_x3
+# at L ~ 983 are what gets compared with the reference).  One live-reference run is ~20-40 s of CPU.
+FULL_CASES = {
+    "nl12_full_en_greedy": dict(num_layers=12, seed=0, eos_gain=0.0, preset="librispeech_1", n_text=100, lang="en", top_k=1,
+                                force_eos_at=600, useed=None, full=True),
+    "nl12_full_zh_greedy": dict(num_layers=12, seed=0, eos_gain=0.0, preset="paimon", n_text=100, lang="zh", top_k=1,
+                                force_eos_at=600, useed=None, full=True, text_seed=1),
+    "nl12_full_ja_greedy": dict(num_layers=12, seed=0, eos_gain=0.0, preset="cafe", n_text=100, lang="ja", top_k=1,
+                                force_eos_at=600, useed=None, full=True, text_seed=2),
+    "nl12_full_en_topk10": dict(num_layers=12, seed=0, eos_gain=0.0, preset="librispeech_1", n_text=100, lang="en", top_k=10,
+                                force_eos_at=600, useed=1234, full=True, text_seed=3),
+    "nl12_full_zh_topk10": dict(num_layers=12, seed=0, eos_gain=0.0, preset="paimon", n_text=100, lang="zh", top_k=10,
+                                force_eos_at=600, useed=2345, full=True, text_seed=4),
+    "nl12_full_ja_topk10": dict(num_layers=12, seed=0, eos_gain=0.0, preset="cafe", n_text=100, lang="ja", top_k=10,
+                                force_eos_at=600, useed=3456, full=True, text_seed=5),
+}
+FULL_LOGIT_EVERY = 50          # AR logits are stored for steps 0, 50, ..., 550 (+ the forced-EOS step is not stored)
+
 # VALLE.continual (models/vallex.py:688-787): text ids + a full (T, 8) code matrix; NAR stages only
 CONTINUAL_CASES = {
     "nl2_continual": dict(num_layers=2, seed=6, eos_gain=1.0, n_text=14, frames=61),          # prefix_len = 30
@@ -92,7 +113,7 @@ def case_inputs(c):
     else:
         a, t = synth.synth_prompt(*c["synth_prompt"], seed=c["seed"])
         pl = c["prompt_lang"]
-    txt = synth.synth_text(c["n_text"], c["seed"])[None]
+    txt = synth.synth_text(c["n_text"], c.get("text_seed", c["seed"]))[None]
     text = np.concatenate([t, txt], -1)
     if c["lang"] == "mix":
         langs = [("en", "zh", "ja")[i % 3] for i in range(c["n_text"])]
@@ -114,15 +135,22 @@ def run_reference(c):
     assert not missing.missing_keys and not missing.unexpected_keys
     a, t, text, pl, langs = case_inputs(c)
 
-    rec = {"logits": [], "step": 0}
+    full = bool(c.get("full"))
+    rec = {"logits": [], "step": 0, "margin": []}
     orig_sampling = V.topk_sampling
     orig_multinomial = torch.multinomial
     nbeam = c.get("best_of", 1)
     us = None if c["useed"] is None else synth.uniforms(4096, nbeam, c["useed"])
 
     def hooked(logits, top_k=10, top_p=1.0, temperature=1.0):
-        if rec["step"] < 8:
+        if (rec["step"] % FULL_LOGIT_EVERY == 0) if full else (rec["step"] < 8):
             rec["logits"].append(logits[0].detach().clone().numpy())
+        if full and c["top_k"] == 1:
+            # decision margin of the reference itself: gap between its two largest logits.  A step whose gap is below the
+            # fp32 reassociation noise (~1e-5 here) is one the reference does not decide reproducibly either
+            # (its logits move by 7e-7 with the thread count).
+            top2 = torch.topk(logits[0], 2).values
+            rec["margin"].append(float(top2[0] - top2[1]))
         tok, lp = orig_sampling(logits, top_k=top_k, top_p=top_p, temperature=temperature)
         if c["force_eos_at"] is not None and rec["step"] >= c["force_eos_at"]:
             tok = torch.full_like(tok, synth.EOS_ID)
@@ -132,18 +160,31 @@ def run_reference(c):
     def multinomial(probs, num_samples=1, **kw):
         if us is None:
             return orig_multinomial(probs, num_samples, **kw)
+        if full:
+            # margin of the inverse-CDF decision: distance of u * total to the nearest CDF boundary, in probability units
+            cdf = torch.cumsum(probs[0].double(), 0)
+            rec["margin"].append(float(torch.min(torch.abs(cdf / cdf[-1] - float(us[rec["step"], 0])))))
         return torch.tensor([[inverse_cdf_sample(probs[i], float(us[rec["step"], i]))] for i in range(probs.shape[0])],
                             dtype=torch.long)
 
     nar_logits = []
-    orig_nar_pred = m.nar_predict_layers[0].forward
+    nar_margin = []
 
-    def nar_pred(xx):
-        out = orig_nar_pred(xx)
-        nar_logits.append(out.detach().clone().numpy())
-        return out
+    def hook_stage(j):
+        orig = m.nar_predict_layers[j].forward
 
-    m.nar_predict_layers[0].forward = nar_pred
+        def nar_pred(xx):
+            out = orig(xx)
+            nar_logits.append(out.detach().clone().numpy())
+            if full:
+                t2 = torch.topk(out[0], 2, dim=-1).values
+                nar_margin.append(float((t2[:, 0] - t2[:, 1]).min()))
+            return out
+
+        m.nar_predict_layers[j].forward = nar_pred
+
+    for j in range(7 if full else 1):
+        hook_stage(j)
     V.topk_sampling = hooked
     torch.multinomial = multinomial
     try:
@@ -156,6 +197,12 @@ def run_reference(c):
     finally:
         V.topk_sampling = orig_sampling
         torch.multinomial = orig_multinomial
+    if full:
+        return dict(codes=codes.numpy().astype(np.int64),
+                    ar_logits=np.stack(rec["logits"]).astype(np.float32),                     # steps 0, 50, ..., 550
+                    nar_logits=np.stack([l[0, :16] for l in nar_logits]).astype(np.float32),  # [7 stages][16 frames][1024]
+                    ar_margin=np.array(rec["margin"], np.float64),                            # per AR step (see hooks)
+                    nar_margin=np.array(nar_margin, np.float64))                              # per stage: min top-2 gap
     return dict(codes=codes.numpy().astype(np.int64),
                 ar_logits=np.stack(rec["logits"]).astype(np.float32),
                 nar_logits0=nar_logits[0][0, :16].astype(np.float32))
@@ -191,12 +238,19 @@ def main(only=None):
         out = run_reference_continual(c)
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
         print(name, out["codes"].shape, out["codes"][0, :4, 1], flush=True)
-    for name, c in list(CASES.items()) + list(SHARP_CASES.items()):
+    for name, c in list(CASES.items()) + list(SHARP_CASES.items()) + list(FULL_CASES.items()):
         if only and name not in only:
             continue
+        if c.get("full") and not only and os.path.exists(os.path.join(GOLD, name + ".npz")):
+            continue                                   # full-length runs are slow: regenerate only when named
+        import time
+        t0 = time.time()
         out = run_reference(c)
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
-        print(name, out["codes"].shape, out["codes"][0, :4, 0], flush=True)
+        extra = ""
+        if c.get("full"):
+            extra = f" min AR margin {out['ar_margin'].min():.3e}, min NAR margin {out['nar_margin'].min():.3e}"
+        print(name, out["codes"].shape, out["codes"][0, :4, 0], f"{time.time() - t0:.1f}s" + extra, flush=True)
 
 
 if __name__ == "__main__":

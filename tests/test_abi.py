@@ -30,9 +30,52 @@ def test_header_symbols_exported(lib):
 def test_struct_layout_matches_header():
     import ctypes as C
     from vallex_amd._capi import vx_batch, vx_config, vx_sampling
-    assert C.sizeof(vx_config) == 9 * 4
-    assert vx_batch.text_lens.offset == 32 and C.sizeof(vx_batch) == 64
-    assert vx_sampling.seed.offset == 24 and vx_sampling.best_of.offset == 40 and C.sizeof(vx_sampling) == 56
+    # every descriptor starts with struct_size (ABI guard, include/vallex_hip.h)
+    assert vx_config.struct_size.offset == vx_batch.struct_size.offset == vx_sampling.struct_size.offset == 0
+    assert C.sizeof(vx_config) == 10 * 4
+    assert vx_batch.text_ids.offset == 8 and vx_batch.text_lens.offset == 32 and C.sizeof(vx_batch) == 64
+    assert vx_sampling.uniforms.offset == 16 and vx_sampling.seed.offset == 32 and vx_sampling.best_of.offset == 48
+    assert C.sizeof(vx_sampling) == 64
+
+
+def test_header_struct_fields_match_binding():
+    """field names and order of the three descriptor structs in include/vallex_hip.h == the ctypes binding"""
+    from vallex_amd._capi import vx_batch, vx_config, vx_sampling
+    hdr = open(os.path.join(ROOT, "include", "vallex_hip.h")).read()
+    for st in (vx_config, vx_batch, vx_sampling):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (st.__name__, st.__name__), hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = re.findall(r"(\w+)\s*;", body)
+        assert names == [f[0] for f in st._fields_], (st.__name__, names)
+
+
+def test_abi_version_and_struct_size_guard(lib):
+    """a caller compiled against an older / shorter struct is rejected with VX_EINVAL instead of being read past its end"""
+    import ctypes as C
+    from vallex_amd._capi import ABI_VERSION, VX_EINVAL, vx_config
+    hdr = open(os.path.join(ROOT, "include", "vallex_hip.h")).read()
+    assert int(re.search(r"#define VX_ABI_VERSION (\d+)", hdr).group(1)) == ABI_VERSION == lib.vx_abi_version()
+    ctx = C.c_void_p()
+    short = vx_config(C.sizeof(vx_config) - 4, 2, 1, 8, 8, 8, 1, 0, 0, 0)          # e.g. a struct without `with_encodec`
+    assert lib.vx_create(0, C.byref(short), C.byref(ctx)) == VX_EINVAL
+    assert b"struct_size" in lib.vx_last_error(None)
+
+
+def test_integration_md_stub_matches_binding():
+    """the ctypes structs a maintainer would paste from INTEGRATION.md have the binding's exact layout"""
+    import ctypes as C
+    from vallex_amd import _capi
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = max(re.findall(r"```python\n(.*?)```", md, re.S), key=len)
+    classes = re.findall(r"(class vx_\w+\(C\.Structure\):.*?)(?=\nclass |\n\ndef |\ndef )", block, re.S)
+    assert len(classes) == 3, len(classes)
+    ns = {"C": C}
+    exec("\n".join(classes), ns)
+    for name in ("vx_config", "vx_batch", "vx_sampling"):
+        mine, theirs = getattr(_capi, name), ns[name]
+        assert C.sizeof(mine) == C.sizeof(theirs), name
+        assert [(f[0], getattr(mine, f[0]).offset) for f in mine._fields_] == \
+               [(f[0], getattr(theirs, f[0]).offset) for f in theirs._fields_], name
 
 
 def test_fails_loudly_without_gpu(lib):

@@ -1,0 +1,47 @@
+"""CPU: `python bench.py --gpus 2` starts two ranks BY ITSELF (no launcher), they rendezvous over gloo, shard the job's rows
+contiguously, time with barrier + max-over-ranks and gather the results after the timed region -- the N > 1 code path of
+bench.py with a stub engine (`--stub`: no GPU, nothing measured).  Also the launcher form the driver uses."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def _check(j, n):
+    assert j["n_gpus"] == n and j["scaling"] == "weak"
+    assert j["config"]["rows_total"] == 4 * n and j["config"]["rows_per_gpu"] == 4
+    pr = sorted(j["per_rank"], key=lambda d: d["rank"])
+    assert [d["rank"] for d in pr] == list(range(n))
+    assert [d["rows"] for d in pr] == [[4 * r, 4 * r + 4] for r in range(n)]      # row r -> rank r // rows_per_gpu
+    frames_all = 2 * 4 * n * 10                                                   # steps x rows x frames
+    assert abs(j["value"] * (j["ms_per_step"] * 2 / 1e3) - frames_all / 75.0) < 1e-2 * frames_all / 75.0
+
+
+def test_bench_gpus2_spawns_two_ranks():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "4",
+                        "--frames", "10", "--stub"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _check(_json_line(r.stdout), 2)
+
+
+def test_bench_under_torchrun_launcher():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--rows", "4", "--frames", "10", "--stub"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _check(_json_line(r.stdout), 2)

@@ -138,9 +138,6 @@ def _codes_agree_up_to_ties(got, gold, emb, dec_sd, tol=1e-3):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("VX_RUN_UNVALIDATED") != "1",
-                    reason="vx_encodec_encode was written after this round's GPU budget was spent (oracle and data flow pinned on "
-                           "CPU); set VX_RUN_UNVALIDATED=1 for its first hardware run")
 def test_hip_encoder_matches_transformers_port():
     from tests._util import get_model
     m = get_model(2, 0, 2.5, max_new=64, max_batch=4)

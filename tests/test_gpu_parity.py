@@ -258,9 +258,6 @@ def test_engine_rejects_bad_arguments():
                           temperature=0.0)
 
 
-@pytest.mark.skipif(os.environ.get("VX_RUN_UNVALIDATED") != "1",
-                    reason="written after this round's GPU budget was spent (oracle side pinned to the live reference on CPU, "
-                           "test_oracle_golden.py); set VX_RUN_UNVALIDATED=1 for its first hardware run")
 @pytest.mark.parametrize("name", sorted(CONTINUAL_CASES))
 def test_continual_matches_reference(name):
     """`VALLE.continual` (models/vallex.py:688-787) through vx_nar with language id -1 (= no language embedding):
@@ -273,8 +270,6 @@ def test_continual_matches_reference(name):
     np.testing.assert_array_equal(out, golden(name)["codes"])
 
 
-@pytest.mark.skipif(os.environ.get("VX_RUN_UNVALIDATED") != "1",
-                    reason="goldens added after this round's GPU budget was spent; set VX_RUN_UNVALIDATED=1 for the first hardware run")
 @pytest.mark.parametrize("name", sorted(SHARP_CASES))
 def test_infer_matches_reference_tokens_sharp_attention(name):
     """The attn_gain-3 goldens (peaky attention: sensitive to K/V precision and score arithmetic) through the C ABI."""

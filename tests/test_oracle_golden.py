@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 
 from oracle import synth
-from oracle.make_golden import CASES, CONTINUAL_CASES, GOLD, SHARP_CASES, case_inputs, continual_inputs
+from oracle.make_golden import (CASES, CONTINUAL_CASES, FULL_CASES, FULL_LOGIT_EVERY, GOLD, SHARP_CASES, case_inputs,
+                                continual_inputs)
 from oracle.vallex_oracle import VallexOracle
 
 FAST = [n for n in CASES if n.startswith("nl2_")]
@@ -80,3 +81,30 @@ def test_oracle_matches_reference_tokens_sharp_attention(name):
     codes = orc.inference(text, np.array([text.shape[-1]]), a, t.shape[-1], top_k=c["top_k"], prompt_language=pl,
                           text_language=langs, uniforms=us, force_eos_at=c["force_eos_at"])
     np.testing.assert_array_equal(codes, np.load(os.path.join(GOLD, name + ".npz"))["codes"])
+
+
+# one full-length case by default (~40 s on 8 cores); VX_SLOW=1 runs all six
+FULL_DEFAULT = ["nl12_full_ja_topk10"]
+
+
+@pytest.mark.parametrize("name", sorted(FULL_CASES) if os.environ.get("VX_SLOW") == "1" else FULL_DEFAULT)
+def test_oracle_matches_reference_full_length(name):
+    """BASELINE C1-C3 shape (12 layers, preset + 100 ids, 600 frames, Ltot ~ 983): oracle ids == live reference ids for all
+    600 x 8 tokens, AR logits at every 50th step and the NAR logits of all 7 stages within fp32 reassociation distance."""
+    c = FULL_CASES[name]
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    assert g["codes"].shape == (1, 600, 8)
+    orc = VallexOracle(synth.vallex_state_dict(c["num_layers"], c["seed"], c["eos_gain"]), c["num_layers"])
+    a, t, text, pl, langs = case_inputs(c)
+    us = None if c["useed"] is None else synth.uniforms(4096, 1, c["useed"])[:, 0]
+    taps = {}
+    codes = orc.inference(text, np.array([text.shape[-1]]), a, t.shape[-1], top_k=c["top_k"], prompt_language=pl,
+                          text_language=langs, uniforms=us, force_eos_at=c["force_eos_at"], taps=taps)
+    np.testing.assert_array_equal(codes, g["codes"])
+    # the golden holds steps 0, 50, ..., 600 (step 600 is the sampling call that was forced to EOS)
+    n = min(len(taps["ar_logits"]), 601)
+    ar = np.stack([taps["ar_logits"][i].numpy() for i in range(0, n, FULL_LOGIT_EVERY)])
+    np.testing.assert_allclose(ar, g["ar_logits"][: len(ar)], atol=2e-4, rtol=0)
+    assert len(ar) >= 12
+    for st in range(7):
+        np.testing.assert_allclose(taps["nar_logits"][st][:16].numpy(), g["nar_logits"][st], atol=5e-3, rtol=0)

@@ -24,27 +24,29 @@ class VallexHipError(RuntimeError):
 
 
 class vx_config(C.Structure):
-    _fields_ = [("num_layers", C.c_int32), ("max_batch", C.c_int32), ("max_text", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32), ("num_layers", C.c_int32), ("max_batch", C.c_int32), ("max_text", C.c_int32),
                 ("max_prompt", C.c_int32), ("max_new", C.c_int32), ("use_graph", C.c_int32),
                 ("with_vocos", C.c_int32), ("debug_taps", C.c_int32), ("with_encodec", C.c_int32)]
 
 
 class vx_batch(C.Structure):
-    _fields_ = [("batch", C.c_int32), ("text_ids", C.POINTER(C.c_int32)), ("text_lang", C.POINTER(C.c_int32)),
+    _fields_ = [("struct_size", C.c_uint32), ("batch", C.c_int32), ("text_ids", C.POINTER(C.c_int32)), ("text_lang", C.POINTER(C.c_int32)),
                 ("text_stride", C.c_int32), ("text_lens", C.POINTER(C.c_int32)),
                 ("prompt_codes", C.POINTER(C.c_int32)), ("prompt_stride", C.c_int32),
                 ("prompt_lens", C.POINTER(C.c_int32))]
 
 
 class vx_sampling(C.Structure):
-    _fields_ = [("top_k", C.c_int32), ("temperature", C.c_float), ("uniforms", C.POINTER(C.c_float)),
+    _fields_ = [("struct_size", C.c_uint32), ("top_k", C.c_int32), ("temperature", C.c_float), ("uniforms", C.POINTER(C.c_float)),
                 ("uniforms_steps", C.c_int32), ("seed", C.c_uint64), ("force_eos_at", C.c_int32),
                 ("sync_every", C.c_int32), ("best_of", C.c_int32), ("length_penalty", C.c_float),
                 ("return_worst", C.c_int32)]
 
 
 # every symbol include/vallex_hip.h declares (tests/test_abi.py checks the library exports exactly these)
-SYMBOLS = ["vx_create", "vx_destroy", "vx_last_error", "vx_synchronize", "vx_load_tensor", "vx_finalize_weights",
+ABI_VERSION = 2       # VX_ABI_VERSION of include/vallex_hip.h this binding was written against
+
+SYMBOLS = ["vx_abi_version", "vx_create", "vx_destroy", "vx_last_error", "vx_synchronize", "vx_load_tensor", "vx_finalize_weights",
            "vx_infer", "vx_vocos_decode", "vx_encodec_decode", "vx_encodec_encode", "vx_ar_prefill", "vx_ar_logits", "vx_ar_step",
            "vx_nar", "vx_read_tap",
            "vx_prof_enable", "vx_prof_get", "vx_prof_reset", "vx_bench_kernel", "vx_bench_gemm", "vx_bench_attn", "vx_last_stats"]
@@ -61,6 +63,10 @@ def load_library() -> C.CDLL:
         raise OSError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
     lib = C.CDLL(LIB_PATH)
+    lib.vx_abi_version.argtypes = []
+    lib.vx_abi_version.restype = C.c_int32
+    if lib.vx_abi_version() != ABI_VERSION:
+        raise OSError(f"{LIB_PATH} speaks ABI version {lib.vx_abi_version()}, this binding {ABI_VERSION}: rebuild the library")
     P = C.POINTER
     ctx = C.c_void_p
     lib.vx_create.argtypes = [C.c_int, P(vx_config), P(ctx)]
@@ -92,7 +98,7 @@ def load_library() -> C.CDLL:
     lib.vx_last_stats.argtypes = [ctx, P(C.c_int64), P(C.c_int64), P(C.c_double), P(C.c_double)]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("vx_destroy", "vx_last_error", "vx_read_tap"):
+        if name not in ("vx_destroy", "vx_last_error", "vx_read_tap", "vx_abi_version"):
             fn.restype = C.c_int
     _lib = lib
     return lib
@@ -120,7 +126,7 @@ class Batch:
             self.text_lang[i, : len(texts[i])] = text_langs[i]
             if prompts[i].shape[0]:
                 self.prompt_codes[i, : prompts[i].shape[0]] = prompts[i]
-        self.c = vx_batch(n, _ptr(self.text_ids, C.c_int32), _ptr(self.text_lang, C.c_int32), ts,
+        self.c = vx_batch(C.sizeof(vx_batch), n, _ptr(self.text_ids, C.c_int32), _ptr(self.text_lang, C.c_int32), ts,
                           _ptr(self.text_lens, C.c_int32), _ptr(self.prompt_codes, C.c_int32), ps,
                           _ptr(self.prompt_lens, C.c_int32))
 
@@ -132,7 +138,7 @@ class Engine:
                  max_prompt: int = 1024, max_new: int = 2048, use_graph: bool = True, with_vocos: bool = True,
                  debug_taps: bool = False, with_encodec: bool = False):
         self.lib = load_library()
-        self.cfg = vx_config(num_layers, max_batch, max_text, max_prompt, max_new, int(use_graph), int(with_vocos),
+        self.cfg = vx_config(C.sizeof(vx_config), num_layers, max_batch, max_text, max_prompt, max_new, int(use_graph), int(with_vocos),
                              int(debug_taps), int(with_encodec))
         self.ctx = C.c_void_p()
         rc = self.lib.vx_create(device_id, C.byref(self.cfg), C.byref(self.ctx))
@@ -176,7 +182,7 @@ class Engine:
     def _sampling(n, top_k, temperature, uniforms, seed, force_eos_at, sync_every, best_of=1, length_penalty=1.0,
                   return_worst=False):
         u = None
-        s = vx_sampling(int(top_k), float(temperature), None, 0, int(seed), -1 if force_eos_at is None else int(force_eos_at),
+        s = vx_sampling(C.sizeof(vx_sampling), int(top_k), float(temperature), None, 0, int(seed), -1 if force_eos_at is None else int(force_eos_at),
                         int(sync_every), int(best_of), float(length_penalty), int(bool(return_worst)))
         if best_of > 1:
             n = int(best_of)

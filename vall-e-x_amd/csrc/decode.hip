@@ -671,8 +671,9 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
   const int ngen = a.n_gen[b];
   float u;
   if (a.uniforms) u = a.uniforms[(long)ngen * a.uniforms_stride + b];
-  else u = (float)(splitmix64(a.seed ^ ((unsigned long long)ngen << 24) ^ (unsigned long long)b) >> 40) *
-           (1.0f / 16777216.0f);
+  else   // counter-based: seed, row and step each pass through their own mixing round (no (seed, row) aliasing)
+    u = (float)(splitmix64(splitmix64(splitmix64(a.seed) + (unsigned long long)b) + (unsigned long long)ngen) >> 40) *
+        (1.0f / 16777216.0f);
   const float thresh = u * total;
   float c = incl - loc;
   int cand = 0x7fffffff, lastnz = -1;

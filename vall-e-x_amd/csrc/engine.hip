@@ -48,6 +48,7 @@ struct vx_ctx {
   vx_config cfg{};
   int dev = 0;
   hipStream_t stream = nullptr;
+  hipEvent_t ev_t[3] = {nullptr, nullptr, nullptr};   // AR / NAR phase timing of vx_infer (created once, vx_create)
   std::string err;
   std::map<std::string, Tensor> w;
   bool finalized = false;
@@ -291,7 +292,10 @@ int full_layer(vx_ctx* c, const LayerW& L, long M, const int* seq_off, const int
 
 int check_batch(vx_ctx* c, const vx_batch* b, int max_rows) {
   if (!c->finalized) FAIL(VX_ESTATE, "weights not finalized");
-  if (!b || b->batch <= 0 || b->batch > max_rows) FAIL(VX_EINVAL, "batch must be in 1..%d", max_rows);
+  if (!b) FAIL(VX_EINVAL, "null batch");
+  if (b->struct_size != sizeof(vx_batch))
+    FAIL(VX_EINVAL, "vx_batch.struct_size is %u, this library expects %zu (ABI version %d)", b->struct_size, sizeof(vx_batch), VX_ABI_VERSION);
+  if (b->batch <= 0 || b->batch > max_rows) FAIL(VX_EINVAL, "batch must be in 1..%d", max_rows);
   for (int i = 0; i < b->batch; ++i) {
     const int S = b->text_lens[i], Tp = b->prompt_lens[i];
     if (S <= 0) FAIL(VX_EINVAL, "x_lens must be > 0 (models/vallex.py:493)");       // assert torch.all(x_lens > 0)
@@ -584,8 +588,10 @@ int nar_generate(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::vector
     snprintf(nm, sizeof nm, "nar_predict_layers.%d.weight", st);
     proj(c, c->fxn, D_MODEL, W(c, nm), c->pred_w3[st], nullptr, nullptr, 0, c->flogits, AUDIO_VOCAB, sumT, AUDIO_VOCAB, D_MODEL,
          ACT_NONE, mb.dev(o_gr));
-    if (c->cfg.debug_taps && st == 0)
-      if (int e = tap_store(c, "nar_logits0", c->flogits, (size_t)sumT * AUDIO_VOCAB)) return e;
+    if (c->cfg.debug_taps) {                             // "nar_logits0" .. "nar_logits6": every stage's logits of the generated rows
+      snprintf(nm, sizeof nm, "nar_logits%d", st);
+      if (int e = tap_store(c, nm, c->flogits, (size_t)sumT * AUDIO_VOCAB)) return e;
+    }
     int* samples = c->imeta + o_samples + (long)st * sumT;
     launch_argmax_rows(c->flogits, AUDIO_VOCAB, (int)sumT, AUDIO_VOCAB, samples, c->stream);
     if (st < N_Q - 2) {
@@ -633,8 +639,15 @@ extern "C" {
 
 const char* vx_last_error(const vx_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
+int32_t vx_abi_version(void) { return VX_ABI_VERSION; }
+
 int vx_create(int device_id, const vx_config* cfg, vx_ctx** out) {
   if (!cfg || !out) { g_create_err = "null argument"; return VX_EINVAL; }
+  if (cfg->struct_size != sizeof(vx_config)) {
+    g_create_err = "vx_config.struct_size is " + std::to_string(cfg->struct_size) + ", this library expects " +
+                   std::to_string(sizeof(vx_config)) + " (ABI version " + std::to_string(VX_ABI_VERSION) + ")";
+    return VX_EINVAL;
+  }
   if (cfg->num_layers <= 0 || cfg->max_batch <= 0 || cfg->max_text <= 0 || cfg->max_prompt < 0 || cfg->max_new <= 0) {
     g_create_err = "invalid vx_config";
     return VX_EINVAL;
@@ -657,6 +670,12 @@ int vx_create(int device_id, const vx_config* cfg, vx_ctx** out) {
   };
   if ((e = hipSetDevice(device_id)) != hipSuccess) return fail(e, "hipSetDevice");
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+  for (auto& ev : c->ev_t)
+    if ((e = hipEventCreate(&ev)) != hipSuccess) {
+      for (auto& e2 : c->ev_t) if (e2) (void)hipEventDestroy(e2);
+      (void)hipStreamDestroy(c->stream);
+      return fail(e, "hipEventCreate");
+    }
   *out = c;
   return VX_OK;
 }
@@ -667,6 +686,7 @@ void vx_destroy(vx_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
   for (auto& p : c->prof) for (auto ev : p.ev) (void)hipEventDestroy(ev);
+  for (auto ev : c->ev_t) if (ev) (void)hipEventDestroy(ev);
   for (void* p : c->allocs) (void)hipFree(p);
   for (auto& kv : c->w) (void)hipFree(kv.second.d);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -946,7 +966,7 @@ int vx_finalize_weights(vx_ctx* c) {
       HIPCHK(hipMemcpy(c->vc_dft, dft.data(), dft.size() * sizeof(float), hipMemcpyHostToDevice));
       HIPCHK(hipMemcpy(c->vc_win2, win2.data(), win2.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    c->v_rows_cap = (long)c->cfg.max_batch * c->cfg.max_new;
+    c->v_rows_cap = std::max<long>((long)c->cfg.max_batch * c->cfg.max_new, 512);   // frames per decode pass (longer inputs: windows)
     const long R = c->v_rows_cap + 128;
     if ((e = dev_alloc(c, &c->vfeat, (size_t)R * 128))) return e;
     if ((e = dev_alloc(c, &c->vcol, (size_t)R * 896))) return e;
@@ -956,7 +976,7 @@ int vx_finalize_weights(vx_ctx* c) {
     if ((e = dev_alloc(c, &c->vo, (size_t)R * NBP))) return e;
     if ((e = dev_alloc(c, &c->vreim, (size_t)R * KP))) return e;
     if ((e = dev_alloc(c, &c->vframes, (size_t)R * NF))) return e;
-    if ((e = dev_alloc(c, &c->vaudio, (size_t)c->cfg.max_batch * c->cfg.max_new * 320))) return e;
+    if ((e = dev_alloc(c, &c->vaudio, (size_t)R * 320))) return e;
     c->has_vocos = true;
   }
   // ---- EnCodec SEANet decoder (optional; data/tokenizer.py:95-96 path) ----
@@ -1220,8 +1240,13 @@ int vx_nar(vx_ctx* c, const vx_batch* b, const int32_t* codes0, int32_t codes0_s
   HIPCHK(hipSetDevice(c->dev));
   if (int e = check_batch(c, b, c->mbr)) return e;
   std::vector<int> T(lens, lens + b->batch);
-  for (int i = 0; i < b->batch; ++i)
-    if (T[i] < 0 || T[i] > c->cfg.max_new || T[i] > out_stride) FAIL(VX_EINVAL, "row %d: bad length %d", i, T[i]);
+  for (int i = 0; i < b->batch; ++i) {
+    if (T[i] < 0 || T[i] > c->cfg.max_new || T[i] > out_stride || T[i] > codes0_stride) FAIL(VX_EINVAL, "row %d: bad length %d", i, T[i]);
+    for (int t = 0; t < T[i]; ++t) {                    // indexes nar_audio_embeddings.0 (1025 rows) on the device
+      const int v = codes0[(long)i * codes0_stride + t];
+      if (v < 0 || v > AUDIO_VOCAB) FAIL(VX_EINVAL, "row %d: first-codebook id %d out of range (0..1024)", i, v);
+    }
+  }
   std::vector<int> oc;
   long sumT = 0;
   if (int e = nar_generate(c, b, 0, b->batch, T, codes0, codes0_stride, oc, sumT)) return e;
@@ -1241,6 +1266,8 @@ int vx_infer(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int64_t* out_co
              int32_t* out_lens) {
   if (!c || !s || !out_codes || !out_lens) return VX_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
+  if (s->struct_size != sizeof(vx_sampling))
+    FAIL(VX_EINVAL, "vx_sampling.struct_size is %u, this library expects %zu (ABI version %d)", s->struct_size, sizeof(vx_sampling), VX_ABI_VERSION);
   if (int e = check_batch(c, b, c->cfg.max_batch)) return e;
   if (!(s->temperature > 0.f)) FAIL(VX_EINVAL, "temperature must be > 0");
   c->st_steps = 0; c->st_frames = 0; c->st_ar_ms = 0; c->st_nar_ms = 0;
@@ -1258,7 +1285,7 @@ int vx_infer(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int64_t* out_co
       memcpy(&lg[(size_t)i * S], b->text_lang, S * sizeof(int));
       if (Tp) memcpy(&pc[(size_t)i * Tp * N_Q], b->prompt_codes, (size_t)Tp * N_Q * sizeof(int));
     }
-    vx_batch rb{N, ids.data(), lg.data(), S, tl.data(), pc.data(), std::max(Tp, 1), pl.data()};
+    vx_batch rb{(uint32_t)sizeof(vx_batch), N, ids.data(), lg.data(), S, tl.data(), pc.data(), std::max(Tp, 1), pl.data()};
     std::vector<int> n_gen, gen, oc;
     if (int e = ar_generate(c, &rb, s, 0, N, n_gen, gen)) return e;
     std::vector<float> slp(N);
@@ -1285,8 +1312,7 @@ int vx_infer(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int64_t* out_co
     }
     return VX_OK;
   }
-  hipEvent_t e0, e1, e2;
-  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
+  hipEvent_t e0 = c->ev_t[0], e1 = c->ev_t[1], e2 = c->ev_t[2];      // owned by the context: nothing to leak on an early return
   for (int r0 = 0; r0 < b->batch; r0 += c->mbr) {
     const int nb = std::min(c->mbr, b->batch - r0);
     std::vector<int> n_gen, gen, oc;
@@ -1314,7 +1340,6 @@ int vx_infer(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int64_t* out_co
       off += n_gen[i];
     }
   }
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
   return VX_OK;
 }
 
@@ -1322,61 +1347,91 @@ int vx_vocos_decode(vx_ctx* c, const int64_t* codes, int32_t codes_stride, const
                     int32_t bandwidth_id, float* audio, int64_t audio_stride) {
   if (!c || !codes || !lens || !audio) return VX_EINVAL;
   if (!c->finalized || !c->has_vocos) FAIL(VX_ESTATE, "Vocos weights not loaded");
-  if (batch <= 0 || batch > c->cfg.max_batch) FAIL(VX_EINVAL, "bad batch");
+  if (batch <= 0) FAIL(VX_EINVAL, "bad batch");
   if (bandwidth_id < 0 || bandwidth_id > 3) FAIL(VX_EINVAL, "bandwidth_id must be 0..3");
   HIPCHK(hipSetDevice(c->dev));
   const int C = 384, H = 1152, NBP = 1408, KP = 1312, NF = 1280;
-  std::vector<int> seq_off(batch), seq_len(batch), row_t, row_len, cd;
-  long R = 0;
-  int maxT = 0;
+  // The reference decodes any total length in one call (utils/generation.py:148-150, :271-273 for a whole long text).  The
+  // arena holds `cap` frames, so the rows are cut into JOBS: a row that fits is one job; a longer row is cut into windows
+  // whose centre [a, b) is decoded together with HALO frames of real context on each side.  Every op of the head is local in
+  // time (9 convolutions of 7 taps = 27 frames of reach, per-frame LayerNorm / GEMMs, ISTFT overlap of 3 frames), so the
+  // centre samples are the same floating-point operations in the same order as in a single full-length pass: bit-identical.
+  constexpr int HALO = 32;
+  const long cap = c->v_rows_cap;
+  struct Job { int row, a, b, lo, hi; };
+  std::vector<Job> jobs;
   for (int i = 0; i < batch; ++i) {
     const int T = lens[i];
-    if (T < 0 || T > c->cfg.max_new || T > codes_stride) FAIL(VX_EINVAL, "row %d: bad length", i);
+    if (T < 0 || T > codes_stride) FAIL(VX_EINVAL, "row %d: bad length", i);
     if ((long)T * 320 > audio_stride) FAIL(VX_EINVAL, "audio_stride too small");
-    seq_off[i] = (int)R; seq_len[i] = T; maxT = std::max(maxT, T);
-    for (int t = 0; t < T; ++t) {
-      row_t.push_back(t); row_len.push_back(T);
-      for (int q = 0; q < N_Q; ++q) {
-        const int64_t v = codes[((long)i * codes_stride + t) * N_Q + q];
-        if (v < 0 || v >= AUDIO_VOCAB) FAIL(VX_EINVAL, "code out of range");
-        cd.push_back((int)v);
-      }
+    for (long t = 0; t < (long)T * N_Q; ++t) {
+      const int64_t v = codes[(long)i * codes_stride * N_Q + t];
+      if (v < 0 || v >= AUDIO_VOCAB) FAIL(VX_EINVAL, "code out of range");
     }
-    R += T;
+    if (T == 0) continue;
+    if (T <= cap) { jobs.push_back({i, 0, T, 0, T}); continue; }
+    const int Wc = (int)cap - 2 * HALO;
+    for (int a = 0; a < T; a += Wc) {
+      const int bb = std::min(T, a + Wc);
+      jobs.push_back({i, a, bb, std::max(0, a - HALO), std::min(T, bb + HALO)});
+    }
   }
-  if (R == 0) return VX_OK;
-  if (R > c->v_rows_cap) FAIL(VX_EINVAL, "too many frames");
-  MetaBuilder mb(c);
-  const long o_off = mb.add(seq_off), o_len = mb.add(seq_len), o_rt = mb.add(row_t), o_rl = mb.add(row_len), o_cd = mb.add(cd);
-  if (int e = upload_meta(c)) return e;
   hipStream_t st = c->stream;
   const std::string P = "vocos.backbone.";
-  launch_codebook_sum(mb.dev(o_cd), W(c, "vocos.feature_extractor.codebook_weights"), c->vfeat, (int)R, st);
-  launch_im2col7(c->vfeat, 128, mb.dev(o_rt), mb.dev(o_rl), c->vcol, (int)R, st);
-  gemm(c, c->vcol, 896, c->vc_embed_w, 896, W(c, P + "embed.bias"), nullptr, 0, nullptr, c->vx0, C, R, C, 896, ACT_NONE);
-  launch_layernorm(c->vx0, C, c->vx0, C, (int)R, C, 1e-6f, nullptr, nullptr, W(c, P + "norm.scale.weight") + bandwidth_id * C,
-                   W(c, P + "norm.shift.weight") + bandwidth_id * C, st);
-  for (int i = 0; i < 8; ++i) {
-    const std::string p = P + "convnext." + std::to_string(i) + ".";
-    launch_dwconv7(c->vx0, W(c, p + "dwconv.weight"), W(c, p + "dwconv.bias"), mb.dev(o_rt), mb.dev(o_rl), c->vx1, (int)R, C, st);
-    launch_layernorm(c->vx1, C, c->vx1, C, (int)R, C, 1e-6f, nullptr, nullptr, W(c, p + "norm.scale.weight") + bandwidth_id * C,
-                     W(c, p + "norm.shift.weight") + bandwidth_id * C, st);
-    gemm(c, c->vx1, C, W(c, p + "pwconv1.weight"), C, W(c, p + "pwconv1.bias"), nullptr, 0, nullptr, c->vhid, H, R, H, C, ACT_GELU);
-    gemm(c, c->vhid, H, W(c, p + "pwconv2.weight"), H, W(c, p + "pwconv2.bias"), c->vx0, C, W(c, p + "gamma"), c->vx0, C, R, C, H,
-         ACT_NONE);
+  size_t j0 = 0;
+  while (j0 < jobs.size()) {
+    size_t j1 = j0;
+    long R = 0;
+    while (j1 < jobs.size() && R + (jobs[j1].hi - jobs[j1].lo) <= cap) { R += jobs[j1].hi - jobs[j1].lo; ++j1; }
+    const int nj = (int)(j1 - j0);
+    std::vector<int> seq_off(nj), seq_len(nj), row_t, row_len, cd;
+    row_t.reserve(R); row_len.reserve(R); cd.reserve(R * N_Q);
+    long off = 0;
+    int maxT = 0;
+    for (int j = 0; j < nj; ++j) {
+      const Job& jb = jobs[j0 + j];
+      const int T = jb.hi - jb.lo;
+      seq_off[j] = (int)off; seq_len[j] = T; maxT = std::max(maxT, T);
+      for (int t = 0; t < T; ++t) {
+        row_t.push_back(t); row_len.push_back(T);
+        for (int q = 0; q < N_Q; ++q) cd.push_back((int)codes[((long)jb.row * codes_stride + jb.lo + t) * N_Q + q]);
+      }
+      off += T;
+    }
+    MetaBuilder mb(c);
+    const long o_off = mb.add(seq_off), o_len = mb.add(seq_len), o_rt = mb.add(row_t), o_rl = mb.add(row_len), o_cd = mb.add(cd);
+    if (int e = upload_meta(c)) return e;
+    launch_codebook_sum(mb.dev(o_cd), W(c, "vocos.feature_extractor.codebook_weights"), c->vfeat, (int)R, st);
+    launch_im2col7(c->vfeat, 128, mb.dev(o_rt), mb.dev(o_rl), c->vcol, (int)R, st);
+    gemm(c, c->vcol, 896, c->vc_embed_w, 896, W(c, P + "embed.bias"), nullptr, 0, nullptr, c->vx0, C, R, C, 896, ACT_NONE);
+    launch_layernorm(c->vx0, C, c->vx0, C, (int)R, C, 1e-6f, nullptr, nullptr, W(c, P + "norm.scale.weight") + bandwidth_id * C,
+                     W(c, P + "norm.shift.weight") + bandwidth_id * C, st);
+    for (int i = 0; i < 8; ++i) {
+      const std::string p = P + "convnext." + std::to_string(i) + ".";
+      launch_dwconv7(c->vx0, W(c, p + "dwconv.weight"), W(c, p + "dwconv.bias"), mb.dev(o_rt), mb.dev(o_rl), c->vx1, (int)R, C, st);
+      launch_layernorm(c->vx1, C, c->vx1, C, (int)R, C, 1e-6f, nullptr, nullptr, W(c, p + "norm.scale.weight") + bandwidth_id * C,
+                       W(c, p + "norm.shift.weight") + bandwidth_id * C, st);
+      gemm(c, c->vx1, C, W(c, p + "pwconv1.weight"), C, W(c, p + "pwconv1.bias"), nullptr, 0, nullptr, c->vhid, H, R, H, C, ACT_GELU);
+      gemm(c, c->vhid, H, W(c, p + "pwconv2.weight"), H, W(c, p + "pwconv2.bias"), c->vx0, C, W(c, p + "gamma"), c->vx0, C, R, C, H,
+           ACT_NONE);
+    }
+    launch_layernorm(c->vx0, C, c->vx1, C, (int)R, C, 1e-6f, W(c, P + "final_layer_norm.weight"), W(c, P + "final_layer_norm.bias"),
+                     nullptr, nullptr, st);
+    gemm(c, c->vx1, C, c->vc_head_w, C, c->vc_head_b, nullptr, 0, nullptr, c->vo, NBP, R, NBP, C, ACT_NONE);
+    launch_istft_prep(c->vo, NBP, c->vreim, KP, (int)R, st);
+    gemm(c, c->vreim, KP, c->vc_dft, KP, nullptr, nullptr, 0, nullptr, c->vframes, NF, R, NF, KP, ACT_NONE);
+    // audio of job j lands packed at sample offset seq_off[j] * 320 (audio_stride 0 = packed)
+    launch_overlap_add(c->vframes, NF, mb.dev(o_off), mb.dev(o_len), c->vc_win2, c->vaudio, 0, nj, maxT, st);
+    for (int j = 0; j < nj; ++j) {
+      const Job& jb = jobs[j0 + j];
+      HIPCHK(hipMemcpyAsync(audio + (long)jb.row * audio_stride + (long)jb.a * 320,
+                            c->vaudio + ((long)seq_off[j] + (jb.a - jb.lo)) * 320, (size_t)(jb.b - jb.a) * 320 * sizeof(float),
+                            hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    j0 = j1;
   }
-  launch_layernorm(c->vx0, C, c->vx1, C, (int)R, C, 1e-6f, W(c, P + "final_layer_norm.weight"), W(c, P + "final_layer_norm.bias"),
-                   nullptr, nullptr, st);
-  gemm(c, c->vx1, C, c->vc_head_w, C, c->vc_head_b, nullptr, 0, nullptr, c->vo, NBP, R, NBP, C, ACT_NONE);
-  launch_istft_prep(c->vo, NBP, c->vreim, KP, (int)R, st);
-  gemm(c, c->vreim, KP, c->vc_dft, KP, nullptr, nullptr, 0, nullptr, c->vframes, NF, R, NF, KP, ACT_NONE);
-  const long astride = (long)c->cfg.max_new * 320;
-  launch_overlap_add(c->vframes, NF, mb.dev(o_off), mb.dev(o_len), c->vc_win2, c->vaudio, astride, batch, maxT, st);
-  for (int i = 0; i < batch; ++i)
-    HIPCHK(hipMemcpyAsync(audio + (long)i * audio_stride, c->vaudio + (long)i * astride, (size_t)lens[i] * 320 * sizeof(float),
-                          hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  HIPCHK(hipGetLastError());
   return VX_OK;
 }
 
@@ -1638,14 +1693,17 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
     HIPCHK(hipMemcpyAsync(c->ctx_len, ctx.data(), nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->active, one.data(), nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    const LayerW& L = c->ar[0];
-    for (int w = 0; w < 3; ++w)
-      launch_dec_attn(c->p_qkv, SK_QKV, L.in_b, c->kc, c->vc, c->Tmax, c->ctx_len, c->active, c->xp_att, c->part_o,
-                      c->part_ml, c->nsplit, nb, c->stream);
+    // rotate over the layers' KV arenas like the real step does: the working set (NL x ~178 MB at batch 32) is far beyond
+    // the 256 MiB Infinity Cache, so no launch is served from it
+    const size_t cache_layer = (size_t)c->mbr * N_HEAD * c->Tmax * D_HEAD;
+    auto attn_l = [&](int r) {
+      const int l = r % c->NL;
+      launch_dec_attn(c->p_qkv, SK_QKV, c->ar[l].in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax, c->ctx_len,
+                      c->active, c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, c->stream);
+    };
+    for (int w = 0; w < 3; ++w) attn_l(w);
     HIPCHK(hipEventRecord(e0, c->stream));
-    for (int r = 0; r < reps; ++r)
-      launch_dec_attn(c->p_qkv, SK_QKV, L.in_b, c->kc, c->vc, c->Tmax, c->ctx_len, c->active, c->xp_att, c->part_o,
-                      c->part_ml, c->nsplit, nb, c->stream);
+    for (int r = 0; r < reps; ++r) attn_l(r);
     HIPCHK(hipEventRecord(e1, c->stream));
     launches = reps;
   } else if (which == 1) {

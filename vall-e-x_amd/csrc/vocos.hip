@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restric
     acc += frames[(base + f) * (long)ldf + n];
     env += win2[n];
   }
-  audio[(long)b * audio_stride + s] = acc / env;
+  // audio_stride 0: the sequences' audio is packed like their frames (sample offset seq_off * hop)
+  audio[(audio_stride ? (long)b * audio_stride : base * VC_HOP) + s] = acc / env;
 }
 
 void launch_overlap_add(const float* frames, int ldf, const int* seq_off, const int* seq_len, const float* win2,

@@ -34,6 +34,15 @@ def _np(a, dtype=None):
     return a.astype(dtype) if dtype is not None else a
 
 
+def fresh_seed() -> int:
+    """Seed of the device sampler for ONE call.  The reference samples from torch's global generator (torch.multinomial,
+    models/vallex.py:850): repeated calls differ, `torch.manual_seed` makes a script reproducible.  Same contract here:
+    every call that is not given an explicit `seed=` draws a new 62-bit seed from that generator."""
+    if torch is not None:
+        return int(torch.randint(0, 2 ** 62, (1,)).item())
+    return int(np.random.default_rng().integers(0, 2 ** 62))
+
+
 def expected_keys(num_layers: int) -> List[str]:
     """State-dict layout of the reference (models/vallex.py:55-264,405-445)."""
     k = ["ar_text_embedding.word_embeddings.weight", "nar_text_embedding.word_embeddings.weight",
@@ -185,7 +194,7 @@ class VALLE:
     def inference(self, x, x_lens, y, enroll_x_lens, top_k: int = -100, temperature: float = 1.0,
                   prompt_language: str = None, text_language: Union[str, List[str]] = None, best_of: int = 1,
                   length_penalty: float = 1.0, return_worst: bool = False, *, uniforms=None, force_eos_at=None,
-                  seed: int = 0):
+                  seed: Optional[int] = None):
         xa, xl, ya = _np(x), _np(x_lens), _np(y)
         assert xa.ndim == 2, xa.shape                      # models/vallex.py:488-493
         assert xl.ndim == 1, xl.shape
@@ -225,10 +234,12 @@ class VALLE:
         return torch.from_numpy(out) if torch is not None else out
 
     def inference_batch(self, rows: Sequence[dict], top_k: int = -100, temperature: float = 1.0, uniforms=None,
-                        force_eos_at=None, seed: int = 0, sync_every: int = 8, best_of: int = 1,
+                        force_eos_at=None, seed: Optional[int] = None, sync_every: int = 8, best_of: int = 1,
                         length_penalty: float = 1.0, return_worst: bool = False) -> List[np.ndarray]:
         """rows[i] = dict(text ids (S,), prompt codes (Tp,8), enroll, prompt_language, text_language).
         Row i equals `inference` run alone on that row.  Returns one (T_i, 8) int64 array per row."""
+        if seed is None:
+            seed = fresh_seed()
         texts, langs, prompts = [], [], []
         for r in rows:
             t = _np(r["text"], np.int32).reshape(-1)

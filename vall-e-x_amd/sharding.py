@@ -15,6 +15,18 @@ def shard_range(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + q + (1 if rank < r else 0)
 
 
+def gather_rows(lo: int, mine: Sequence, n_rows: int, dist) -> List:
+    """The one collective of the multi-GPU path: every rank contributes the results of its contiguous shard [lo, lo+len(mine))
+    and gets the results of all `n_rows` rows back in job order (`all_gather_object`; RCCL on GPUs, gloo in the CPU tests)."""
+    world = dist.get_world_size()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (lo, list(mine)))
+    out: List = [None] * n_rows
+    for lo_r, part in gathered:
+        out[lo_r: lo_r + len(part)] = part
+    return out
+
+
 def infer_sharded(rows: Sequence, infer_fn: Callable[[Sequence], List], dist=None) -> List:
     """Run `infer_fn` on this rank's shard and return the results of ALL rows, in the original order, on every rank.
     `dist` is an initialised torch.distributed module (or None for a single process)."""
@@ -24,9 +36,4 @@ def infer_sharded(rows: Sequence, infer_fn: Callable[[Sequence], List], dist=Non
     lo, hi = shard_range(len(rows), world, rank)
     mine = list(infer_fn(rows[lo:hi])) if hi > lo else []
     assert len(mine) == hi - lo
-    gathered = [None] * world
-    dist.all_gather_object(gathered, (lo, mine))
-    out: List = [None] * len(rows)
-    for lo_r, part in gathered:
-        out[lo_r: lo_r + len(part)] = part
-    return out
+    return gather_rows(lo, mine, len(rows), dist)
