@@ -6,7 +6,11 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import vallex_amd  # noqa: E402
+import vallex_amd
+from vallex_amd import _capi
+
+# the probes live in the tools-only build: python vall-e-x_amd/_build.py --dev
+_capi.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dev", "libvallex_hip.so")  # noqa: E402
 
 eng = vallex_amd.Engine(num_layers=1, max_batch=1, max_text=8, max_prompt=8, max_new=8, with_vocos=False)
 for B, L in ((32, 988), (8, 77)):

@@ -6,12 +6,16 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vallex_amd  # noqa: E402
+from vallex_amd import _capi  # noqa: E402
+
+# the probes live in the tools-only build: python vall-e-x_amd/_build.py --dev
+_capi.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dev", "libvallex_hip.so")
 
 eng = vallex_amd.Engine(num_layers=1, max_batch=1, max_text=8, max_prompt=8, max_new=8, with_vocos=False)
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 31616
 for (N, K) in ((3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)):
     row = [f"N={N:5d} K={K:5d}"]
-    for k, name in ((1, "x3"), (2, "x3-dma"), (21, "dma-noDMA"), (22, "dma-noMFMA"), (23, "dma-nofrag"), (24, "dma-nobarrier"), (3, "x3-ring"), (5, "x3-pipe"), (6, "f16x2")):
+    for k, name in ((1, "x3"), (2, "x3-dma"), (21, "dma-noDMA"), (22, "dma-noMFMA"), (23, "dma-nofrag"), (24, "dma-nobarrier"), (6, "f16x2")):
         us, md = eng.bench_gemm(M, N, K, k, 5)
         row.append(f"{name}: {us:8.1f} us {2.0 * M * N * K / us / 1e6:6.1f} TF diff {md:.2e}")
     print("  |  ".join(row), flush=True)

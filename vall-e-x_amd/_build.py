@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libvallex_hip.so")
-SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "gemm_bf16x3_dma.hip", "gemm_bf16x3_ring.hip", "gemm_bf16x3_pipe.hip", "gemm_f16x2_dma.hip", "rows.hip", "attn_full.hip", "attn_full_x3.hip", "decode.hip", "vocos.hip", "encodec.hip", "engine.hip"]
+SOURCES = ["gemm_f32.hip", "gemm_f16x2.hip", "gemm_bf16x3.hip", "gemm_bf16x3_dma.hip", "rows.hip", "attn_full.hip", "attn_full_x3.hip", "decode.hip", "vocos.hip", "encodec.hip", "engine.hip"]
 HEADERS = ["vx_common.h", os.path.join("..", "..", "include", "vallex_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
 
@@ -21,36 +21,67 @@ def _hipcc() -> str:
     return "hipcc"
 
 
-def _stale(target: str, deps) -> bool:
-    if not os.path.exists(target):
+def _digest(paths, extra=()) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    for e in extra:
+        h.update(str(e).encode())
+    return h.hexdigest()
+
+
+def _stale(target: str, deps, extra=()) -> bool:
+    """Content-keyed, not mtime-keyed: an object is reused only if the digest of its source, the headers and the flags equals
+    the one recorded when it was compiled (`<target>.sha256`); a stale or foreign .o/.so that travelled with a snapshot is
+    rebuilt."""
+    stamp = target + ".sha256"
+    if not os.path.exists(target) or not os.path.exists(stamp):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    return open(stamp).read().strip() != _digest(deps, extra)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
+def _stamp(target: str, deps, extra=()):
+    with open(target + ".sha256", "w") as f:
+        f.write(_digest(deps, extra))
+
+
+def build_library(force: bool = False, verbose: bool = False, dev: bool = False) -> str:
+    """dev=True: a SEPARATE library with the kernels' timing probes compiled in (-DVX_DEV_PROBES), for tools/gemm_bench.py and
+    tools/attn_bench.py only (tools/dev/libvallex_hip.so); the product library never contains them."""
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
+    out_dir = os.path.join(os.path.dirname(HERE), "tools", "dev") if dev else CSRC
+    os.makedirs(out_dir, exist_ok=True)
+    lib = os.path.join(out_dir, "libvallex_hip.so")
+    flags = FLAGS + (["-DVX_DEV_PROBES"] if dev else [])
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        obj = os.path.join(out_dir, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src] + hdrs):
-            jobs.append([_hipcc()] + FLAGS + ["-c", src, "-o", obj])
+        if force or _stale(obj, [src] + hdrs, flags):
+            jobs.append(([_hipcc()] + flags + ["-c", src, "-o", obj], obj, [src] + hdrs))
 
-    def run(cmd):
+    def run(job):
+        cmd, target, deps = job
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        _stamp(target, deps, flags if target.endswith(".o") else ())
 
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    relinked = False
+    if force or jobs or _stale(lib, objs):
+        run(([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, lib, objs))
+        relinked = True
+    print(f"[build] {len(jobs)} of {len(SOURCES)} sources compiled for gfx950, library {'linked' if relinked else 'up to date (content digests match)'}",
+          flush=True)
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_library(force="--force" in sys.argv, verbose=True, dev="--dev" in sys.argv))

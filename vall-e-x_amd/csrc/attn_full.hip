@@ -236,6 +236,7 @@ void launch_attn_full(const float* qkv, float* out, const int* seq_off, const in
                      prefix_len, nqb);
 }
 
+#ifdef VX_DEV_PROBES   // timing probes: tools-only build (vall-e-x_amd/_build.py --dev), never in the product library
 void launch_attn_full_probe(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
                             int batch, int max_len, int variant, hipStream_t s) {
   const int nqb = (max_len + QB - 1) / QB;
@@ -244,5 +245,7 @@ void launch_attn_full_probe(const float* qkv, float* out, const int* seq_off, co
   else if (variant == 2) hipLaunchKernelGGL(attn_full_kernel<2>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
   else hipLaunchKernelGGL(attn_full_kernel<3>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
 }
+
+#endif
 
 }  // namespace vx

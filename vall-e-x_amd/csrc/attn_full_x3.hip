@@ -426,12 +426,15 @@ void launch_attn_full_x3(const float* qkv, float* out, const int* seq_off, const
   if (batch <= 0 || max_len <= 0) return;
   const int nqb = (max_len + QB - 1) / QB;                   // batch * N_HEAD is a multiple of 8 (16 heads)
   const dim3 grid(nqb * N_HEAD * batch), block(256);
+#ifdef VX_DEV_PROBES
   if (variant == 1) hipLaunchKernelGGL(attn_full_x3_kernel<1>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
   else if (variant == 2) hipLaunchKernelGGL(attn_full_x3_kernel<2>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
   else if (variant == 3) hipLaunchKernelGGL(attn_full_x3_kernel<3>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
   else if (variant == 4) hipLaunchKernelGGL(attn_full_x3_kernel<4>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
   else if (variant == 5) hipLaunchKernelGGL(attn_full_x3_kernel<5>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
-  else hipLaunchKernelGGL(attn_full_x3_kernel<0>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
+  else
+#endif
+  hipLaunchKernelGGL(attn_full_x3_kernel<0>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
 }
 
 }  // namespace vx

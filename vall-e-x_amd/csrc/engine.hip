@@ -70,15 +70,12 @@ struct vx_ctx {
   int Tmax = 0;                    // KV rows per (row, head)
   long Mmax = 0;                   // packed rows of a micro-batch on the full-sequence paths
 
-  // bf16x3 GEMM path (default) for the transformer projections of prefill / NAR; VX_GEMM_F32=1 keeps the fp32 MFMA
-  bool x3 = true;
-  bool gemm_h2 = false;                       // VX_GEMM_H2=1: EXPERIMENT gemm_f16x2_dma.hip (fp16 head + scaled tail, 3 MFMAs per block, ~2^-22)
-  bool gemm_pipe = false;                     // VX_GEMM_PIPE=1: gemm_bf16x3_pipe.hip (4-stage ring + fragment prefetch across the rendezvous), k-step-major planes
-  bool gemm_ring = false;                     // VX_GEMM_RING=1: 256x256 three-stage ring kernel (gemm_bf16x3_ring.hip, k-step-major planes).
-                                              // +4 % on the isolated GEMM, no end-to-end gain over the DMA kernel; kept selectable
-  bool gemm_dma = true;                       // async-LDS bf16x3 GEMM (gemm_bf16x3_dma.hip); VX_GEMM_DMA=0 keeps the register-staged one
+  // arithmetic of the transformer projections of prefill / NAR: 0 = f16x2 (default; gemm_f16x2.hip), 1 = bf16x3
+  // (VX_GEMM_X3=1; gemm_bf16x3*.hip), 2 = exact fp32 MFMA (VX_GEMM_F32=1; gemm_f32.hip).  All three keep every golden's ids.
+  int gemm_mode = 0;
   bool attn_x3 = true;                        // bf16x3 attention (attn_full_x3.hip); VX_ATTN_F32=1 keeps the fp32 MFMA kernel
-  unsigned short* fa3 = nullptr;   // activation planes [3][M][K<=4096]
+  int* range_flag = nullptr;       // device flag: an operand of an f16x2 GEMM did not fit fp16 (checked after every phase)
+  unsigned short* fa3 = nullptr;   // activation planes [2 or 3][M][K<=4096]
   unsigned short* pred_w3[N_Q - 1] = {};
   // full-sequence arena
   float *fx = nullptr, *fxn = nullptr, *fqkv = nullptr, *fatt = nullptr, *fffn = nullptr, *fyemb = nullptr,
@@ -241,30 +238,22 @@ void gemm(vx_ctx* c, const float* A, int lda, const float* Wt, int ldw, const fl
   launch_gemm_f32(g, c->stream);
 }
 
-// transformer projection: bf16x3 on the bf16 matrix cores (default) or the fp32 MFMA kernel
+// transformer projection (F.linear of modules/activation.py:144,166, modules/transformer.py:371-373, models/vallex.py:677)
 void proj(vx_ctx* c, const float* A, int lda, const float* Wf, const unsigned short* W3, const float* bias,
           const float* resid, int ldr, float* C, int ldc, long M, int N, int K, int act, const int* gather = nullptr) {
-  if (!c->x3 || !W3) {
+  if (c->gemm_mode == 2 || !W3) {
     gemm(c, A, lda, Wf, K, bias, resid, ldr, nullptr, C, ldc, M, N, K, act, gather);
     return;
   }
-  const bool k16 = c->gemm_ring || c->gemm_pipe;                 // kernels on k-step-major planes
-  if ((k16 || c->gemm_h2) && M < 1024) {                                // the ring kernel's tiles are 256 rows: short row sets
-    gemm(c, A, lda, Wf, K, bias, resid, ldr, nullptr, C, ldc, M, N, K, act, gather);   // take the exact fp32 kernel
-    return;
-  }
-  if (c->gemm_h2) launch_split2h(A, lda, M, K, gather, c->fa3, (long)M * K, c->stream);
-  else if (k16) launch_split3_k16(A, lda, M, K, gather, c->fa3, (long)M * K, c->stream);
+  if (c->gemm_mode == 0) launch_split2h(A, lda, M, K, gather, c->fa3, (long)M * K, c->range_flag, c->stream);
   else launch_split3(A, lda, M, K, gather, c->fa3, (long)M * K, c->stream);
   GemmX3Args g{};
   g.A = c->fa3; g.a_plane = (long)M * K; g.W = W3; g.w_plane = (long)N * K; g.bias = bias; g.resid = resid; g.ldr = ldr;
   g.colscale = nullptr; g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.act = act;
   ProfScope ps(c, 2);
   if (c->prof_on) c->prof[2].bytes += 2.0 * (double)M * N * K;
-  if (c->gemm_h2) launch_gemm_f16x2_dma(g, c->stream);
-  else if (c->gemm_pipe) launch_gemm_bf16x3_pipe(g, c->stream);
-  else if (c->gemm_ring) launch_gemm_bf16x3_ring(g, c->stream);
-  else if (c->gemm_dma && M >= 1024) launch_gemm_bf16x3_dma(g, c->stream);   // 256-row tiles: not for short row sets
+  if (c->gemm_mode == 0) launch_gemm_f16x2(g, c->stream);
+  else if (M >= 1024) launch_gemm_bf16x3_dma(g, c->stream);        // 256-row tiles: not for short row sets
   else launch_gemm_bf16x3(g, c->stream);
 }
 
@@ -287,6 +276,20 @@ int full_layer(vx_ctx* c, const LayerW& L, long M, const int* seq_off, const int
                    ada2 ? ada2 + D_MODEL : nullptr, c->stream);
   proj(c, c->fxn, D_MODEL, L.l1_w, L.l1_w3, L.l1_b, nullptr, 0, c->fffn, D_FF, M, D_FF, D_MODEL, ACT_RELU);
   proj(c, c->fffn, D_FF, L.l2_w, L.l2_w3, L.l2_b, c->fx, D_MODEL, c->fx, D_MODEL, M, D_MODEL, D_FF, ACT_NONE);
+  return VX_OK;
+}
+
+// f16x2 operands must fit fp16: the split kernels raise a device flag instead of producing inf heads silently
+int check_range_flag(vx_ctx* c, const char* where) {
+  if (c->gemm_mode != 0) return VX_OK;
+  int flag = 0;
+  HIPCHK(hipMemcpyAsync(&flag, c->range_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (flag) {
+    HIPCHK(hipMemsetAsync(c->range_flag, 0, sizeof(int), c->stream));
+    FAIL(VX_EHIP, "%s: an activation or weight of a projection is outside the fp16 range (|x| >= 65504 or non-finite); "
+                  "rerun with VX_GEMM_X3=1 (bf16x3) or VX_GEMM_F32=1", where);
+  }
   return VX_OK;
 }
 
@@ -503,6 +506,7 @@ int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int 
   HIPCHK(hipMemcpyAsync(n_gen.data(), c->n_gen, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(gen.data(), c->gen, gen.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  if (int e = check_range_flag(c, "AR prefill")) return e;
   c->st_steps += steps;
   if (c->prof_on) {
     // algorithmic KV bytes: every decode step of an active row reads ctx rows of K and V in all layers
@@ -602,7 +606,7 @@ int nar_generate(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::vector
   HIPCHK(hipMemcpyAsync(out_codes.data(), c->imeta + o_samples, out_codes.size() * sizeof(int), hipMemcpyDeviceToHost,
                         c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  return VX_OK;
+  return check_range_flag(c, "NAR stages");
 }
 
 int need(vx_ctx* c, const std::string& name, std::initializer_list<int64_t> shape) {
@@ -838,18 +842,16 @@ int vx_finalize_weights(vx_ctx* c) {
     if (t.shape.size() == 2 && t.shape[1] == d && t.shape[0] >= c->Tmax) { c->pe = const_cast<float*>(user_pe); c->pe_rows = (int)t.shape[0]; }
   }
 
-  // ---- bf16 triple planes of every transformer projection used on the full-sequence paths ----
-  if (const char* ev = getenv("VX_GEMM_F32")) c->x3 = !(ev[0] == '1');
+  // ---- 16-bit operand planes of every transformer projection used on the full-sequence paths ----
+  if (const char* ev = getenv("VX_GEMM_X3")) if (ev[0] == '1') c->gemm_mode = 1;
+  if (const char* ev = getenv("VX_GEMM_F32")) if (ev[0] == '1') c->gemm_mode = 2;
   if (const char* ev = getenv("VX_ATTN_F32")) c->attn_x3 = !(ev[0] == '1');
-  if (const char* ev = getenv("VX_GEMM_DMA")) c->gemm_dma = !(ev[0] == '0');
-  if (const char* ev = getenv("VX_GEMM_RING")) c->gemm_ring = (ev[0] == '1');
-  if (const char* ev = getenv("VX_GEMM_PIPE")) c->gemm_pipe = (ev[0] == '1');
-  if (const char* ev = getenv("VX_GEMM_H2")) c->gemm_h2 = (ev[0] == '1');
-  if (c->x3) {
+  if ((e = dev_alloc(c, &c->range_flag, 1))) return e;
+  if (c->gemm_mode != 2) {
+    const int P = c->gemm_mode == 0 ? 2 : 3;
     auto split_w = [&](const float* Wt, int N, int K, unsigned short** out) -> int {
-      if (int e2 = dev_alloc(c, out, (size_t)3 * N * K, false)) return e2;
-      if (c->gemm_h2) launch_split2h(Wt, K, N, K, nullptr, *out, (long)N * K, c->stream);
-      else if (c->gemm_ring || c->gemm_pipe) launch_split3_k16(Wt, K, N, K, nullptr, *out, (long)N * K, c->stream);
+      if (int e2 = dev_alloc(c, out, (size_t)P * N * K, false)) return e2;
+      if (c->gemm_mode == 0) launch_split2h(Wt, K, N, K, nullptr, *out, (long)N * K, c->range_flag, c->stream);
       else launch_split3(Wt, K, N, K, nullptr, *out, (long)N * K, c->stream);
       return VX_OK;
     };
@@ -863,7 +865,7 @@ int vx_finalize_weights(vx_ctx* c) {
       }
     for (int j = 0; j < N_Q - 1; ++j)
       if ((e = split_w(W(c, "nar_predict_layers." + std::to_string(j) + ".weight"), AUDIO_VOCAB, d, &c->pred_w3[j]))) return e;
-    if ((e = dev_alloc(c, &c->fa3, (size_t)3 * (c->Mmax + 128) * f, false))) return e;
+    if ((e = dev_alloc(c, &c->fa3, (size_t)P * (c->Mmax + 128) * f, false))) return e;
   }
 
   // ---- packed decode images of the AR stack ----
@@ -1196,6 +1198,7 @@ int vx_finalize_weights(vx_ctx* c) {
   }
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipGetLastError());
+  if ((e = check_range_flag(c, "vx_finalize_weights"))) return e;
   c->finalized = true;
   return VX_OK;
 }
@@ -1735,12 +1738,15 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
 }
 
 // Stand-alone GEMM micro-benchmark on scratch buffers (kernel development aid; never on the product path):
-// kernel 0 = gemm_f32, 1 = gemm_bf16x3, 2 = gemm_bf16x3_dma, 3 = gemm_bf16x3_ring, 4 = ring4, 5 = pipe, 6 = f16x2 (experiment);
-// 11-13 / 21-24 = timing probes of the register-staged / DMA kernel (results meaningless).  Reports the average launch time and the max abs
-// difference of the first 256 output rows against the fp32-MFMA kernel.
+// kernel 0 = gemm_f32, 1 = gemm_bf16x3, 2 = gemm_bf16x3_dma, 6 = gemm_f16x2 (the default of the model path);
+// 11-13 / 21-24 = timing probes of the bf16x3 kernels (VX_DEV_PROBES builds only).  Reports the average launch time and the max abs
+// difference of the first and last 256 output rows against the fp32-MFMA kernel.
 int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, int32_t reps, double* avg_us,
                   double* max_abs_diff) {
   if (!c || M <= 0 || N <= 0 || K <= 0 || K % 32 || N % 4 || reps <= 0 || !avg_us || !max_abs_diff) return VX_EINVAL;
+#ifndef VX_DEV_PROBES
+  if (kernel != 0 && kernel != 1 && kernel != 2 && kernel != 6) FAIL(VX_EINVAL, "kernel must be 0, 1, 2 or 6 (probes need a VX_DEV_PROBES build)");
+#endif
   HIPCHK(hipSetDevice(c->dev));
   float *A = nullptr, *Wt = nullptr, *C0 = nullptr, *C1 = nullptr;
   unsigned short *A3 = nullptr, *W3 = nullptr;
@@ -1765,12 +1771,9 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
   GemmArgs g0{};
   g0.A = A; g0.lda = K; g0.W = Wt; g0.ldw = K; g0.C = C0; g0.ldc = N; g0.M = M; g0.N = N; g0.K = K; g0.act = ACT_NONE;
   launch_gemm_f32(g0, c->stream);
-  if (kernel == 6) {                                             // fp16 head / scaled tail planes for the f16x2 experiment
-    launch_split2h(A, K, M, K, nullptr, A3, (long)M * K, c->stream);
-    launch_split2h(Wt, K, N, K, nullptr, W3, (long)N * K, c->stream);
-  } else if (kernel == 3 || kernel == 4 || kernel == 5) {                              // k-step-major planes for the ring kernels
-    launch_split3_k16(A, K, M, K, nullptr, A3, (long)M * K, c->stream);
-    launch_split3_k16(Wt, K, N, K, nullptr, W3, (long)N * K, c->stream);
+  if (kernel == 6) {                                             // fp16 head / scaled tail planes
+    launch_split2h(A, K, M, K, nullptr, A3, (long)M * K, nullptr, c->stream);
+    launch_split2h(Wt, K, N, K, nullptr, W3, (long)N * K, nullptr, c->stream);
   } else {
     launch_split3(A, K, M, K, nullptr, A3, (long)M * K, c->stream);
     launch_split3(Wt, K, N, K, nullptr, W3, (long)N * K, c->stream);
@@ -1784,12 +1787,11 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
     if (kernel == 0) launch_gemm_f32(g1, c->stream);
     else if (kernel == 1) launch_gemm_bf16x3(gx, c->stream);
     else if (kernel == 2) launch_gemm_bf16x3_dma(gx, c->stream);
-    else if (kernel == 3) launch_gemm_bf16x3_ring(gx, c->stream);
-    else if (kernel == 4) launch_gemm_bf16x3_ring4(gx, c->stream);
-    else if (kernel == 5) launch_gemm_bf16x3_pipe(gx, c->stream);
-    else if (kernel == 6) launch_gemm_f16x2_dma(gx, c->stream);
+    else if (kernel == 6) launch_gemm_f16x2(gx, c->stream);
+#ifdef VX_DEV_PROBES
     else if (kernel >= 21) launch_gemm_bf16x3_dma_probe(gx, kernel - 20, c->stream);   // 21-24: probes of the DMA kernel
     else launch_gemm_bf16x3_probe(gx, kernel - 10, c->stream);      // 11 / 12 / 13: timing probes
+#endif
   };
   run();
   // VX_BENCH_CLOCK=1: sample the shader clock on a second stream while the timed launches run (power / clock ceiling check)
@@ -1873,7 +1875,11 @@ int vx_bench_attn(vx_ctx* c, int32_t batch, int32_t len, int32_t causal, int32_t
   const int* pre = causal ? meta + 2 * batch : nullptr;
   auto run = [&]() {
     if (variant == 0) launch_attn_full(qkv, out, meta, meta + batch, pre, batch, len, c->stream);
+#ifdef VX_DEV_PROBES
     else if (variant < 10) launch_attn_full_probe(qkv, out, meta, meta + batch, pre, batch, len, variant, c->stream);
+#else
+    else if (variant < 10) return;
+#endif
     else launch_attn_full_x3(qkv, out, meta, meta + batch, pre, batch, len, variant - 10, c->stream);
   };
   run();

@@ -239,11 +239,14 @@ void launch_gemm_bf16x3(const GemmX3Args& g, hipStream_t s) {
   hipLaunchKernelGGL(gemm_bf16x3_kernel<0>, dim3(tiles), dim3(256), 0, s, g);
 }
 
+#ifdef VX_DEV_PROBES   // timing probes: tools-only build (vall-e-x_amd/_build.py --dev), never in the product library
 void launch_gemm_bf16x3_probe(const GemmX3Args& g, int variant, hipStream_t s) {
   const int tiles = ((g.M + XB_M - 1) / XB_M) * ((g.N + XB_N - 1) / XB_N);
   if (variant == 1) hipLaunchKernelGGL(gemm_bf16x3_kernel<1>, dim3(tiles), dim3(256), 0, s, g);
   else if (variant == 2) hipLaunchKernelGGL(gemm_bf16x3_kernel<2>, dim3(tiles), dim3(256), 0, s, g);
   else hipLaunchKernelGGL(gemm_bf16x3_kernel<3>, dim3(tiles), dim3(256), 0, s, g);
 }
+
+#endif
 
 }  // namespace vx

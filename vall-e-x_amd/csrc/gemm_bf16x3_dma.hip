@@ -207,6 +207,7 @@ void launch_gemm_bf16x3_dma(const GemmX3Args& g, hipStream_t s) {
   hipLaunchKernelGGL(gemm_bf16x3_dma_kernel<0>, dim3(tiles), dim3(512), 0, s, g);
 }
 
+#ifdef VX_DEV_PROBES   // timing probes: tools-only build (vall-e-x_amd/_build.py --dev), never in the product library
 void launch_gemm_bf16x3_dma_probe(const GemmX3Args& g, int variant, hipStream_t s) {
   const int tiles = ((g.M + DM - 1) / DM) * ((g.N + DN - 1) / DN);
   if (tiles <= 0) return;
@@ -216,5 +217,7 @@ void launch_gemm_bf16x3_dma_probe(const GemmX3Args& g, int variant, hipStream_t 
   else if (variant == 3) hipLaunchKernelGGL(gemm_bf16x3_dma_kernel<3>, grid, block, 0, s, g);
   else hipLaunchKernelGGL(gemm_bf16x3_dma_kernel<4>, grid, block, 0, s, g);
 }
+
+#endif
 
 }  // namespace vx

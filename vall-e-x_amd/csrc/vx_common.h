@@ -38,33 +38,29 @@ struct GemmArgs {
 };
 void launch_gemm_f32(const GemmArgs& g, hipStream_t s);
 
-// ---- fp32-accurate GEMM on the bf16 matrix cores (gemm_bf16x3.hip) ------------------------------------------
-// operands are three bf16 planes (x = x1 + x2 + x3), each K-tile-major [K/32][rows][32]; same epilogue contract as
-// GemmArgs.  K % 32 == 0.
+// ---- fp32-class GEMMs on the 16-bit matrix cores ----------------------------------------------------------------
+// Operands are pre-split planes, each K-tile-major [K/32][rows][32] 16-bit; same epilogue contract as GemmArgs.  K % 32 == 0.
+//   f16x2  (gemm_f16x2.hip, DEFAULT): 2 planes  x = h + t/2048 (fp16 head + fp16 tail), 3 f16 MFMAs per product block
+//   bf16x3 (gemm_bf16x3*.hip, VX_GEMM_X3=1): 3 bf16 planes x = x1 + x2 + x3, 6 bf16 MFMAs per product block
 struct GemmX3Args {
-  const unsigned short* A; long a_plane;   // [3][M][K], plane stride in elements
-  const unsigned short* W; long w_plane;   // [3][N][K]
+  const unsigned short* A; long a_plane;   // [P][M][K], plane stride in elements (P = 2 or 3)
+  const unsigned short* W; long w_plane;   // [P][N][K]
   const float* bias; const float* resid; int ldr; const float* colscale;
   float* C; int ldc;
   int M, N, K;
   int act;
 };
-void launch_gemm_bf16x3(const GemmX3Args& g, hipStream_t s);
-void launch_gemm_bf16x3_probe(const GemmX3Args& g, int variant, hipStream_t s);
-void launch_gemm_bf16x3_dma(const GemmX3Args& g, hipStream_t s);
-void launch_gemm_bf16x3_dma_probe(const GemmX3Args& g, int variant, hipStream_t s);   // timing probes 1-4 (tools/gemm_bench.py)
-// gemm_bf16x3_ring.hip: 256x256 tile, k-step stages, 3-deep async ring; planes in k-step-major order [K/16][rows][16]
-void launch_gemm_bf16x3_ring(const GemmX3Args& g, hipStream_t s);
-void launch_gemm_bf16x3_ring4(const GemmX3Args& g, hipStream_t s);
-void launch_gemm_bf16x3_pipe(const GemmX3Args& g, hipStream_t s);
-// EXPERIMENT (bench kernel 6; model path only under VX_GEMM_H2=1): fp16 head + scaled fp16 tail, three f16 MFMAs per block (gemm_f16x2_dma.hip); planes [2][K/32][rows][32]
-void launch_gemm_f16x2_dma(const GemmX3Args& g, hipStream_t s);
+void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s);                 // 256 x 128 x 32 tile, async LDS fill, any M
 void launch_split2h(const float* x, int ldx, long rows, int K, const int* gather, unsigned short* planes, long plane_stride,
-                    hipStream_t s);    // gemm_bf16x3_pipe.hip: 4-stage ring + fragment prefetch   // 4 waves x (128 x 128)
-void launch_split3_k16(const float* x, int ldx, long rows, int K, const int* gather, unsigned short* planes,
-                       long plane_stride, hipStream_t s);   // gemm_bf16x3_dma.hip: async LDS fill, 256x128 tile   // timing probes (tools/gemm_bench.py)
+                    int* range_flag, hipStream_t s);                        // *range_flag = 1 if some |x| does not fit fp16
+void launch_gemm_bf16x3(const GemmX3Args& g, hipStream_t s);                // register-staged 128 x 128 tile (short row sets)
+void launch_gemm_bf16x3_dma(const GemmX3Args& g, hipStream_t s);            // 256 x 128 tile, async LDS fill (M >= 1024)
 void launch_split3(const float* x, int ldx, long rows, int K, const int* gather, unsigned short* planes,
                    long plane_stride, hipStream_t s);
+#ifdef VX_DEV_PROBES
+void launch_gemm_bf16x3_probe(const GemmX3Args& g, int variant, hipStream_t s);
+void launch_gemm_bf16x3_dma_probe(const GemmX3Args& g, int variant, hipStream_t s);
+#endif
 
 // ---- row-wise ops (rows.hip) --------------------------------------------------------------------
 // y = (LN(x) * g + b) [* ada_w + ada_b]; any of g/b/ada_* may be null.  C in {1024, 384}.
@@ -97,11 +93,13 @@ void launch_gemv(const float* W, const float* e, const float* b, float* out, int
 void launch_attn_full(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
                       int batch, int max_len, hipStream_t s);
 
-// bf16x3 version (attn_full_x3.hip), the product path; variant 0 = product, 1-3 = timing probes
+// bf16x3 version (attn_full_x3.hip), the product path; variant 0 = product (1-5 = timing probes, VX_DEV_PROBES builds only)
 void launch_attn_full_x3(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
                          int batch, int max_len, int variant, hipStream_t s);
+#ifdef VX_DEV_PROBES
 void launch_attn_full_probe(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
                             int batch, int max_len, int variant, hipStream_t s);   // timing probes (tools/attn_bench.py)
+#endif
 
 // ---- AR decode step (decode.hip) ---------------------------------------------------------------
 // packed skinny-GEMM weight image: tiles of 32 n-rows x 8 k, lane-linear (see decode.hip)
@@ -116,19 +114,6 @@ void launch_dec_reduce_ln_pack(const float* partial, int splitk, int npad, const
 void launch_pack_weight16(const float* W, int N, int K, float* Wp, hipStream_t s);
 void launch_skinny16_relu_pack(const float* W16, const float* xp, const float* bias, float* xp_out, int N, int K,
                                const int* n_active, hipStream_t s);
-// h[b] = (resid? resid[b] : 0) + sum_ks partial[ks][b] + bias ; xp = pack(LN(h)*g+b)   (N = 1024)
-void launch_dec_reduce_ln_pack(const float* partial, int splitk, int npad, const float* bias, const float* resid,
-                               float* h, const float* g, const float* b, float* xp, int batch, hipStream_t s);
-// linear1 with fused bias+ReLU+pack on 16-row tiles (v_mfma_f32_16x16x4_f32), 256 workgroups, no split-K
-void launch_pack_weight16(const float* W, int N, int K, float* Wp, hipStream_t s);
-void launch_skinny16_relu_pack(const float* W16, const float* xp, const float* bias, float* xp_out, int N, int K,
-                               const int* n_active, hipStream_t s);
-// linear1: raw split-K partials written directly in linear2's packed-x image  out_pk[ks][32 * Npad]
-void launch_skinny_gemm_packed_out(const float* Wp, const float* xp, float* out_pk, int Npad, int K, int splitk,
-                                   hipStream_t s);
-// linear2: operand x = relu(x_pk[0] + x_pk[1] + xbias) formed while loading (xslab = floats between the two slabs)
-void launch_skinny_gemm_relu_in(const float* Wp, const float* x_pk, const float* xbias, long xslab, float* partial,
-                                int Npad, int K, int splitk, hipStream_t s);
 // h[b] = tab[tok[b]] + alpha*pe[pos[b]] ; xp = pack(LN(h))  -- start of a decode step
 void launch_dec_embed_ln_pack(const int* tok, const int* pos, const float* tab, const float* alpha, const float* pe,
                               float* h, const float* g, const float* b, float* xp, int batch, hipStream_t s);
@@ -163,12 +148,12 @@ void launch_lstm_cell(const float* part, int splitk, const float* xg, const int*
 void launch_final_conv(const float* x, const float* w, const float* bias, const int* seq_off, const int* seq_len, int R,
                        float* audio, long audio_stride, int batch, long max_rows, hipStream_t s);
 
-// ---- Vocos head (vocos.hip) --------------------------------------------------------------------
 // encoder side (encodec.hip): first Conv1d(1,32,k7); ELU + causal reflect padding of a strided conv; one residual-VQ step
 void launch_enc_first_conv(const float* wav, long L, const float* w, const float* bias, float* out, hipStream_t s);
 void launch_enc_pad_elu(const float* x, long L, long Le, int C, int left, long rows, float* out, hipStream_t s);
 void launch_rvq_select(float* resid, const float* scores, const float* e2, const float* codebook, long long* codes, int q,
                        long rows, hipStream_t s);
+// ---- Vocos head (vocos.hip) --------------------------------------------------------------------
 void launch_codebook_sum(const int* codes, const float* codebook, float* feat, int rows, hipStream_t s);
 void launch_im2col7(const float* x, int C, const int* row_t, const int* row_len, float* out, int rows, hipStream_t s);
 void launch_dwconv7(const float* x, const float* w, const float* bias, const int* row_t, const int* row_len,
