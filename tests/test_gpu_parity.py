@@ -141,6 +141,22 @@ def test_vocos_head_matches_oracle():
         assert abs(np.sqrt(np.mean(a ** 2)) - np.sqrt(np.mean(ref ** 2))) <= 1e-4
 
 
+def test_vocos_long_input_is_windowed_bit_identically():
+    """an input longer than the Vocos arena (the reference decodes a whole long text in one call, utils/generation.py:271-273)
+    is decoded in overlapping windows: bit-identical to a single pass of an engine whose arena holds it, and within the
+    north_star tolerance of the CPU restatement."""
+    rng = np.random.default_rng(11)
+    codes = [rng.integers(0, 1024, size=(T, 8), dtype=np.int64) for T in (1300, 40)]
+    small = get_model(2, 0, 2.5, vocos=True, max_new=64, max_batch=2)          # arena: 512 frames per pass -> 4 windows for row 0
+    got = small.engine.vocos_decode(codes, 2)
+    big = get_model(2, 0, 2.5, vocos=True, max_new=1400, max_batch=2)          # arena holds both rows in one pass
+    ref = big.engine.vocos_decode(codes, 2)
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)
+    orc = VocosOracle(synth.vocos_state_dict(2)).decode_codes(codes[0][None], 2)[0]
+    assert float(np.sqrt(np.mean((got[0] - orc) ** 2))) <= 1e-4
+
+
 def test_generate_audio_api_end_to_end():
     """utils.generation drop-in: preset .npz in, float32 waveform out; deterministic via injected uniforms, checked
     against reference-arithmetic run on the CPU (oracle AR+NAR, Vocos restatement)."""

@@ -1,0 +1,115 @@
+"""CPU: independent checks of the pieces of the Vocos restatement (oracle/vallex_oracle.py VocosOracle).
+
+The pip `vocos` package and its weights are absent offline, so the restatement as a whole stays "parity unpinned" (DESIGN.md
+section 2).  What CAN be pinned here is that every piece computes what the torch building blocks the package is made of compute:
+  * backbone: the same synthetic weights loaded into torch.nn modules (Conv1d, LayerNorm, Embedding, Linear, GELU) wired like
+    vocos.models.VocosBackbone / vocos.modules.ConvNeXtBlock / AdaLayerNorm (recalled structure);
+  * codes_to_features: nn.Embedding + offsets, vocos.pretrained.Vocos.codes_to_features;
+  * ISTFT head ("same" padding): torch.istft (center=True) on the interior samples, where the two differ only by the 160-sample
+    shift between trimming (n_fft - hop)/2 = 480 and n_fft/2 = 640.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from oracle import synth
+from oracle.vallex_oracle import VocosOracle
+
+C, H, NB = synth.VOCOS_DIM, synth.VOCOS_IDIM, synth.VOCOS_NFFT + 2
+
+
+class AdaLN(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.scale = nn.Embedding(4, C)
+        self.shift = nn.Embedding(4, C)
+        self.ln = nn.LayerNorm(C, eps=1e-6, elementwise_affine=False)
+
+    def forward(self, x, bid):
+        return self.ln(x) * self.scale(bid) + self.shift(bid)
+
+
+class Block(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.dwconv = nn.Conv1d(C, C, 7, padding=3, groups=C)
+        self.norm = AdaLN()
+        self.pwconv1 = nn.Linear(C, H)
+        self.act = nn.GELU()
+        self.pwconv2 = nn.Linear(H, C)
+        self.gamma = nn.Parameter(torch.zeros(C))
+
+    def forward(self, x, bid):
+        r = x
+        x = self.dwconv(x).transpose(1, 2)
+        x = self.pwconv2(self.act(self.pwconv1(self.norm(x, bid))))
+        return r + (self.gamma * x).transpose(1, 2)
+
+
+class Backbone(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.embed = nn.Conv1d(synth.VOCOS_INCH, C, 7, padding=3)
+        self.norm = AdaLN()
+        self.convnext = nn.ModuleList([Block() for _ in range(synth.VOCOS_LAYERS)])
+        self.final_layer_norm = nn.LayerNorm(C, eps=1e-6)
+
+    def forward(self, feat, bid):
+        x = self.embed(feat)
+        x = self.norm(x.transpose(1, 2), bid).transpose(1, 2)
+        for blk in self.convnext:
+            x = blk(x, bid)
+        return self.final_layer_norm(x.transpose(1, 2))
+
+
+def _load(mod, sd):
+    own = mod.state_dict()
+    ren = {}
+    for k, v in sd.items():
+        if not k.startswith("backbone."):
+            continue
+        kk = k[len("backbone."):].replace("norm.scale.weight", "norm.scale.weight").replace("norm.shift.weight", "norm.shift.weight")
+        ren[kk] = torch.from_numpy(v)
+    missing = [k for k in own if k not in ren]
+    assert not missing, missing
+    mod.load_state_dict({k: ren[k] for k in own}, strict=True)
+
+
+def test_backbone_equals_torch_modules():
+    sd = synth.vocos_state_dict(2)
+    orc = VocosOracle(sd)
+    bb = Backbone().eval()
+    _load(bb, sd)
+    feat = torch.randn(2, synth.VOCOS_INCH, 53, generator=torch.Generator().manual_seed(1))
+    for bid in (0, 2):
+        with torch.no_grad():
+            ref = bb(feat, torch.tensor([bid]))
+            got = orc.backbone(feat, bid)
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-5, rtol=1e-5)
+
+
+def test_codes_to_features_equals_embedding_sum():
+    sd = synth.vocos_state_dict(2)
+    orc = VocosOracle(sd)
+    emb = nn.Embedding.from_pretrained(torch.from_numpy(sd["feature_extractor.codebook_weights"]))
+    codes = torch.randint(0, 1024, (8, 2, 31), generator=torch.Generator().manual_seed(3))
+    ref = sum(emb(codes[q] + 1024 * q) for q in range(8)).transpose(1, 2)
+    np.testing.assert_allclose(orc.codes_to_features(codes).numpy(), ref.numpy(), atol=1e-6, rtol=0)
+
+
+def test_istft_head_equals_torch_istft_on_interior_samples():
+    sd = synth.vocos_state_dict(2)
+    orc = VocosOracle(sd)
+    n_fft, hop = synth.VOCOS_NFFT, synth.VOCOS_HOP
+    T = 40
+    x = torch.randn(1, T, C, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        got = orc.head(x)[0]                                            # (320 T,)
+        o = torch.nn.functional.linear(x, orc.w["head.out.weight"], orc.w["head.out.bias"]).transpose(1, 2)
+        mag, p = o.chunk(2, dim=1)
+        S = torch.clip(torch.exp(mag), max=1e2) * (torch.cos(p) + 1j * torch.sin(p))
+        ref = torch.istft(S, n_fft, hop, n_fft, torch.hann_window(n_fft), center=True)[0]   # (320 (T-1),), trims 640 per side
+    assert got.shape[0] == hop * T and ref.shape[0] == hop * (T - 1)
+    shift = n_fft // 2 - (n_fft - hop) // 2                             # 160
+    lo, hi = n_fft, hop * (T - 1) - n_fft                               # fully overlapped region of both
+    np.testing.assert_allclose(got[shift + lo: shift + hi].numpy(), ref[lo:hi].numpy(), atol=2e-5, rtol=1e-5)

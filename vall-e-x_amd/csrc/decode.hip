@@ -260,6 +260,7 @@ __device__ __forceinline__ void ln_pack_row(const f32x4 (&v)[4], int b, const f3
 
 // h[b] = resid[b] + (sum_ks partial[ks][b] + bias);  xp = pack(LN(h)).  partial may be null (splitk = 0).
 // modules/transformer.py:345-346 (x = x + attn_out ; x = x + ff(norm2(x))) fused with the next norm.
+// Slabs are summed in ascending ks order, 8 at a time (all 8 x 4 loads of a chunk in flight together).
 template <int SK>
 __global__ __launch_bounds__(64) void dec_reduce_ln_pack_kernel(const float* __restrict__ partial, int npad,
                                                                 const float* __restrict__ bias,
@@ -268,10 +269,10 @@ __global__ __launch_bounds__(64) void dec_reduce_ln_pack_kernel(const float* __r
                                                                 const float* __restrict__ bb,
                                                                 float* __restrict__ xp) {
   const int b = blockIdx.x, lane = threadIdx.x;
-  f32x4 v[4], gg[4], be[4], r[4], bi[4], p[SK > 0 ? SK : 1][4];
-  // every load of the kernel is independent: issue all of them, then reduce (slab order ks ascending)
+  constexpr int CH = SK > 8 ? 8 : (SK > 0 ? SK : 1);
+  f32x4 v[4], gg[4], be[4], r[4], bi[4], p[CH][4];
 #pragma unroll
-  for (int ks = 0; ks < SK; ++ks)
+  for (int ks = 0; ks < (SK < CH ? SK : CH); ++ks)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       p[ks][i] = *reinterpret_cast<const f32x4*>(partial + ((long)ks * MB + b) * npad + (lane + 64 * i) * 4);
@@ -284,19 +285,32 @@ __global__ __launch_bounds__(64) void dec_reduce_ln_pack_kernel(const float* __r
     if (SK > 0 && bias) bi[i] = *reinterpret_cast<const f32x4*>(bias + c);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (SK > 0) {
-      v[i] = p[0][i];
+  for (int i = 0; i < 4; ++i) v[i] = SK > 0 ? p[0][i] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 1; ks < SK; ++ks)
+  for (int ks = 1; ks < (SK < CH ? SK : CH); ++ks)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] += p[ks][i][e];
+#pragma unroll
+  for (int k0 = CH; k0 < SK; k0 += CH) {
+#pragma unroll
+    for (int ks = 0; ks < CH; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        p[ks][i] = *reinterpret_cast<const f32x4*>(partial + ((long)(k0 + ks) * MB + b) * npad + (lane + 64 * i) * 4);
+#pragma unroll
+    for (int ks = 0; ks < CH; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[i][e] += p[ks][i][e];
-      if (bias)
+  }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[i][e] += bi[i][e];
-    } else {
-      v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+  for (int i = 0; i < 4; ++i) {
+    if (SK > 0 && bias)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] += bi[i][e];
     if (resid)
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[i][e] = r[i][e] + v[i][e];
@@ -307,12 +321,12 @@ __global__ __launch_bounds__(64) void dec_reduce_ln_pack_kernel(const float* __r
 
 void launch_dec_reduce_ln_pack(const float* partial, int splitk, int npad, const float* bias, const float* resid,
                                float* h, const float* g, const float* b, float* xp, int batch, hipStream_t s) {
-  if (splitk == 0)
-    hipLaunchKernelGGL((dec_reduce_ln_pack_kernel<0>), dim3(batch), dim3(64), 0, s, partial, npad, bias, resid, h, g, b, xp);
-  else if (splitk == 4)
-    hipLaunchKernelGGL((dec_reduce_ln_pack_kernel<4>), dim3(batch), dim3(64), 0, s, partial, npad, bias, resid, h, g, b, xp);
-  else
-    hipLaunchKernelGGL((dec_reduce_ln_pack_kernel<8>), dim3(batch), dim3(64), 0, s, partial, npad, bias, resid, h, g, b, xp);
+#define VX_RLP(SKV) hipLaunchKernelGGL((dec_reduce_ln_pack_kernel<SKV>), dim3(batch), dim3(64), 0, s, partial, npad, bias, resid, h, g, b, xp)
+  if (splitk == 0) VX_RLP(0);
+  else if (splitk == 4) VX_RLP(4);
+  else if (splitk == 8) VX_RLP(8);
+  else VX_RLP(16);
+#undef VX_RLP
 }
 
 // Start of a step: embed the newest token of each row at its audio position (the reference re-embeds all of y and
@@ -369,17 +383,32 @@ constexpr int ATT_U = 4;              // rows per lane-group per buffer; two buf
 constexpr int ATT_WAVES = 8;          // 512-thread workgroup
 constexpr int ATT_STRIDE = ATT_WAVES * 4 * ATT_U;   // rows consumed per block iteration
 
-__global__ __launch_bounds__(ATT_WAVES * 64) void dec_attn_kernel(const float* __restrict__ qkv_partial, int splitk,
-                                                                  const float* __restrict__ qkv_bias,
-                                                                  float* __restrict__ kc, float* __restrict__ vc,
-                                                                  int Tmax, const int* __restrict__ ctx_len,
-                                                                  const int* __restrict__ active,
-                                                                  float* __restrict__ xp_out,
-                                                                  float* __restrict__ part_o,
-                                                                  float* __restrict__ part_ml, int nsplit) {
+// FUSE_OUT (only launched with nsplit == 1): out_proj (modules/activation.py:166) is folded into the epilogue.  The
+// workgroup of (head h, row b) multiplies its normalised 64-float head output with the head's 64 columns of W_o and writes
+// the per-head partial  out_h[b][n] = sum_d W_o[n][64h + d] o[d]  (n < 1024); the 16 head slabs are summed in head order by
+// the next kernel's prologue (dec_reduce_ln_pack<16>), exactly like split-K slabs.  W_o is stored head-major,
+// wo_heads[((h * 16 + d/4) * 1024 + n) * 4 + d%4], so a wave reads 1 KiB runs; a head's 256 KiB slice is shared by the 32
+// row-workgroups of that head, which all run on XCDs h % 8 (block id % 8) and find it in that XCD's L2.  This removes one
+// weight-streaming launch + kernel boundary per layer from the latency chain of the step.
+template <bool FUSE_OUT>
+__global__ __launch_bounds__(ATT_WAVES * 64, 4) void dec_attn_kernel(const float* __restrict__ qkv_partial, int splitk,
+                                                                     const float* __restrict__ qkv_bias,
+                                                                     float* __restrict__ kc, float* __restrict__ vc,
+                                                                     int Tmax, const int* __restrict__ ctx_len,
+                                                                     const int* __restrict__ active,
+                                                                     float* __restrict__ xp_out,
+                                                                     float* __restrict__ part_o,
+                                                                     float* __restrict__ part_ml, int nsplit,
+                                                                     const float* __restrict__ wo_heads,
+                                                                     float* __restrict__ out_heads,
+                                                                     const int* __restrict__ row_order) {
   __shared__ __attribute__((aligned(16))) float sh_o[ATT_WAVES][64];
+  __shared__ __attribute__((aligned(16))) float sh_ot[64];
   __shared__ float sh_m[ATT_WAVES], sh_l[ATT_WAVES];
-  const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z;
+  // row_order: launch slot -> batch row.  Workgroups are dispatched in block-id order, two per CU, so slot y and slot
+  // y + batch/2 share a CU: the engine orders the rows so that the long contexts sit in the first half and each is
+  // paired with a short one (ragged batches: every CU streams about the same number of KV bytes).
+  const int h = blockIdx.x, b = row_order ? row_order[blockIdx.y] : blockIdx.y, sp = blockIdx.z;
   if (!active[b]) return;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
   const int ctx = ctx_len[b];                 // cached rows INCLUDING the new token (at ctx-1)
@@ -474,6 +503,14 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void dec_attn_kernel(const float* _
   }
 #undef ATT_LOAD
 #undef ATT_CONSUME
+  // fused out_proj: the first half of this thread's W_o values (n = tid, all 64 d of the head) is requested now -- it
+  // does not depend on the attention result and its L2 latency hides under the group / wave combine below
+  f32x4 wo[16];
+  const f32x4* wh = reinterpret_cast<const f32x4*>(wo_heads) + (long)h * 16 * D_MODEL + threadIdx.x;
+  if (FUSE_OUT) {
+#pragma unroll
+    for (int dg = 0; dg < 16; ++dg) wo[dg] = wh[dg * D_MODEL];
+  }
   // the new token itself (always visible: last mask row is all False, models/vallex.py:535-549)
   if (sp == nsplit - 1 && wid == 0 && g == 0) {
     float d = q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3];
@@ -522,21 +559,59 @@ __global__ __launch_bounds__(ATT_WAVES * 64) void dec_attn_kernel(const float* _
       const float inv = 1.0f / lt;
 #pragma unroll
       for (int e = 0; e < 4; ++e) ot[e] *= inv;
+      if (FUSE_OUT) *reinterpret_cast<f32x4*>(&sh_ot[c * 4]) = ot;
       // column k = h*64 + 4c: kb = h*8 + (c>>1), hi = c&1
-      *reinterpret_cast<f32x4*>(xp_out + (((long)(h * 8 + (c >> 1)) * 64) + b + 32 * (c & 1)) * 4) = ot;
+      else *reinterpret_cast<f32x4*>(xp_out + (((long)(h * 8 + (c >> 1)) * 64) + b + 32 * (c & 1)) * 4) = ot;
     } else {
       const long pi = ((long)(b * N_HEAD + h) * nsplit + sp);
       *reinterpret_cast<f32x4*>(part_o + pi * D_HEAD + c * 4) = ot;
       if (c == 0) { part_ml[pi * 2] = mt; part_ml[pi * 2 + 1] = lt; }
     }
   }
+  if (FUSE_OUT) {
+    __syncthreads();
+    float* dst = out_heads + ((long)h * MB + b) * D_MODEL + threadIdx.x;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float acc = 0.f;
+#pragma unroll
+      for (int dg = 0; dg < 16; ++dg) {
+        const f32x4 o4 = *reinterpret_cast<const f32x4*>(&sh_ot[dg * 4]);       // LDS broadcast
+        acc = fmaf(wo[dg][0], o4[0], acc);
+        acc = fmaf(wo[dg][1], o4[1], acc);
+        acc = fmaf(wo[dg][2], o4[2], acc);
+        acc = fmaf(wo[dg][3], o4[3], acc);
+      }
+      if (half == 0) {
+#pragma unroll
+        for (int dg = 0; dg < 16; ++dg) wo[dg] = wh[dg * D_MODEL + ATT_WAVES * 64];   // n = tid + 512
+      }
+      dst[half * ATT_WAVES * 64] = acc;
+    }
+  }
 }
 
 void launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias, float* kc, float* vc, int Tmax,
                      const int* ctx_len, const int* active, float* xp_out, float* part_o, float* part_ml, int nsplit,
-                     int batch, hipStream_t s) {
-  hipLaunchKernelGGL(dec_attn_kernel, dim3(N_HEAD, batch, nsplit), dim3(ATT_WAVES * 64), 0, s, qkv_partial, splitk,
-                     qkv_bias, kc, vc, Tmax, ctx_len, active, xp_out, part_o, part_ml, nsplit);
+                     int batch, const float* wo_heads, float* out_heads, const int* row_order, hipStream_t s) {
+  if (wo_heads && nsplit == 1)
+    hipLaunchKernelGGL(dec_attn_kernel<true>, dim3(N_HEAD, batch, 1), dim3(ATT_WAVES * 64), 0, s, qkv_partial, splitk,
+                       qkv_bias, kc, vc, Tmax, ctx_len, active, xp_out, part_o, part_ml, 1, wo_heads, out_heads, row_order);
+  else
+    hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(N_HEAD, batch, nsplit), dim3(ATT_WAVES * 64), 0, s, qkv_partial, splitk,
+                       qkv_bias, kc, vc, Tmax, ctx_len, active, xp_out, part_o, part_ml, nsplit, nullptr, nullptr, row_order);
+}
+
+// W_o [1024][1024] -> head-major image for the fused out_proj: out[((h*16 + d/4)*1024 + n)*4 + d%4] = W_o[n][64h + d]
+__global__ __launch_bounds__(256) void pack_wo_heads_kernel(const float* __restrict__ W, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;             // float4 index: (h*16 + dg)*1024 + n
+  if (i >= (long)N_HEAD * 16 * D_MODEL) return;
+  const int n = (int)(i % D_MODEL), hd = (int)(i / D_MODEL);       // hd = h*16 + dg -> k = 4 hd
+  *reinterpret_cast<f32x4*>(out + i * 4) = *reinterpret_cast<const f32x4*>(W + (long)n * D_MODEL + hd * 4);
+}
+
+void launch_pack_wo_heads(const float* W, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(pack_wo_heads_kernel, dim3(N_HEAD * 16 * D_MODEL / 256), dim3(256), 0, s, W, out);
 }
 
 __global__ __launch_bounds__(64) void dec_attn_combine_kernel(const float* __restrict__ part_o,
@@ -575,16 +650,6 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
   return x ^ (x >> 31);
 }
 
-__device__ __forceinline__ float wave_max64(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ int wave_sum64i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
 __device__ __forceinline__ int wave_min64i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
@@ -596,11 +661,46 @@ __device__ __forceinline__ int wave_min64i(int v) {
 // run-to-run deterministic order).
 constexpr int SPL = 17;   // 64 * 17 = 1088 >= 1025
 
+// wave-wide reductions: 4 DPP steps inside the 16-lane rows + two cross-row exchanges; every lane gets the result
+__device__ __forceinline__ float dpp_max16(float x) {
+  int v = __builtin_bit_cast(int, x);
+  x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false)));    // quad_perm [1,0,3,2]
+  v = __builtin_bit_cast(int, x);
+  x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false)));    // quad_perm [2,3,0,1]
+  v = __builtin_bit_cast(int, x);
+  x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false)));   // row_half_mirror
+  v = __builtin_bit_cast(int, x);
+  x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false)));   // row_mirror
+  return x;
+}
+__device__ __forceinline__ float wave_max64f(float x) {
+  x = dpp_max16(x);
+  x = fmaxf(x, __shfl_xor(x, 16, 64));
+  return fmaxf(x, __shfl_xor(x, 32, 64));
+}
+__device__ __forceinline__ int dpp_sum16i(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true);
+  return x;
+}
+__device__ __forceinline__ int wave_sum64i_fast(int x) {
+  x = dpp_sum16i(x);
+  x += __shfl_xor(x, 16, 64);
+  return x + __shfl_xor(x, 32, 64);
+}
+
+// topk_sampling (models/vallex.py:836-853) + the stop rule (:572-598) + -- when a.emb_tab is set -- the start of the NEXT
+// decode step for the row: embedding of the committed token at its position and norm1 of layer 0 in the packed-x image
+// (what dec_embed_ln_pack does as a separate launch).  One launch + one kernel boundary less per step.
 __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
   __shared__ float lg[64 * SPL];
   const int b = blockIdx.x, lane = threadIdx.x;
+  // row state: every scalar the kernel needs, requested up front (independent loads)
   const bool act = a.active[b] != 0;
   if (!act && !a.logits_out) return;
+  const int ngen = a.n_gen[b], pos = a.cur_pos[b], ctx = a.ctx_len[b], tlen = a.text_len[b];
 
   {
     float t[SPL];
@@ -626,6 +726,25 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
   __syncthreads();
   if (!act || !a.commit) return;
 
+  // the draw and the fixed operands of the fused embedding do not depend on the logits: request them now
+  float u;
+  if (a.uniforms) u = a.uniforms[(long)ngen * a.uniforms_stride + b];
+  else   // counter-based: seed, row and step each pass through their own mixing round (no (seed, row) aliasing)
+    u = (float)(splitmix64(splitmix64(splitmix64(a.seed) + (unsigned long long)b) + (unsigned long long)ngen) >> 40) *
+        (1.0f / 16777216.0f);
+  f32x4 pe4[4], gg[4], be[4];
+  float alpha = 0.f;
+  if (a.emb_tab) {
+    alpha = a.emb_alpha[0];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      pe4[i] = *reinterpret_cast<const f32x4*>(a.pe + (long)(pos + 1) * D_MODEL + c);
+      gg[i] = *reinterpret_cast<const f32x4*>(a.ln_g + c);
+      be[i] = *reinterpret_cast<const f32x4*>(a.ln_b + c);
+    }
+  }
+
   float v[SPL];
 #pragma unroll
   for (int j = 0; j < SPL; ++j) v[j] = lg[lane * SPL + j];        // stride 17 floats: conflict-free
@@ -636,23 +755,38 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
   float mx = -INFINITY;
 #pragma unroll
   for (int j = 0; j < SPL; ++j) mx = fmaxf(mx, v[j]);
-  mx = wave_max64(mx);
+  mx = wave_max64f(mx);
 
   if (a.top_k > 0 && a.top_k < AR_LOGITS) {                        // :803-809, ties with the k-th value are kept
-    float thr = mx, prev = INFINITY;
-    int count = 0;
-    while (true) {
+    // fast path: walk down top_k DISTINCT values (one wave reduction each); if exactly top_k logits are >= the last one
+    // there were no ties on the way and it is the k-th largest with multiplicity
+    float thr = mx;
+    for (int it = 1; it < a.top_k && thr != -INFINITY; ++it) {
       float cur = -INFINITY;
 #pragma unroll
-      for (int j = 0; j < SPL; ++j) if (v[j] < prev) cur = fmaxf(cur, v[j]);
-      cur = wave_max64(cur);
-      int cnt = 0;
+      for (int j = 0; j < SPL; ++j) if (v[j] < thr) cur = fmaxf(cur, v[j]);
+      thr = wave_max64f(cur);
+    }
+    int cnt = 0;
 #pragma unroll
-      for (int j = 0; j < SPL; ++j) cnt += (v[j] == cur);
-      count += wave_sum64i(cnt);
-      thr = cur;
-      if (count >= a.top_k || cur == -INFINITY) break;
-      prev = cur;
+    for (int j = 0; j < SPL; ++j) cnt += (v[j] >= thr);
+    if (wave_sum64i_fast(cnt) != a.top_k) {                        // ties (or fewer than k finite logits): exact walk
+      float prev = INFINITY;
+      int count = 0;
+      thr = mx;
+      while (true) {
+        float cur = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) if (v[j] < prev) cur = fmaxf(cur, v[j]);
+        cur = wave_max64f(cur);
+        int c2 = 0;
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) c2 += (v[j] == cur);
+        count += wave_sum64i_fast(c2);
+        thr = cur;
+        if (count >= a.top_k || cur == -INFINITY) break;
+        prev = cur;
+      }
     }
 #pragma unroll
     for (int j = 0; j < SPL; ++j) if (v[j] < thr) v[j] = -INFINITY;
@@ -668,12 +802,6 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
     if (lane >= o) incl += t;
   }
   const float total = __shfl(incl, 63, 64);
-  const int ngen = a.n_gen[b];
-  float u;
-  if (a.uniforms) u = a.uniforms[(long)ngen * a.uniforms_stride + b];
-  else   // counter-based: seed, row and step each pass through their own mixing round (no (seed, row) aliasing)
-    u = (float)(splitmix64(splitmix64(splitmix64(a.seed) + (unsigned long long)b) + (unsigned long long)ngen) >> 40) *
-        (1.0f / 16777216.0f);
   const float thresh = u * total;
   float c = incl - loc;
   int cand = 0x7fffffff, lastnz = -1;
@@ -700,24 +828,55 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
     a.sum_logp[b] += (vt - mx) - logf(total);
   }
 
+  // wave-uniform from here: every lane holds the same tok / state
+  if (a.force_eos_at >= 0 && ngen >= a.force_eos_at) tok = EOS_ID;
+  // stop test: EOS, or (y_len - prompt_len) > 16 * text_len  (models/vallex.py:575-578; y has BOS: 1 + ngen); the arena
+  // cap (ngen >= gen_stride) is reported to the host as a truncation (vx_last_truncated)
+  const bool stop = tok == EOS_ID || (1 + ngen) > 16 * tlen || ngen >= a.gen_stride;
   if (lane == 0) {
-    if (a.force_eos_at >= 0 && ngen >= a.force_eos_at) tok = EOS_ID;
-    // stop test: EOS, or (y_len - prompt_len) > 16 * text_len  (models/vallex.py:575-578; y has BOS: 1 + ngen)
-    if (tok == EOS_ID || (1 + ngen) > 16 * a.text_len[b] || ngen >= a.gen_stride) {
+    if (stop) {
       a.active[b] = 0;
       if (a.n_active) atomicSub(a.n_active, 1);
     } else {
       a.gen[(long)b * a.gen_stride + ngen] = tok;
       a.n_gen[b] = ngen + 1;
       a.cur_tok[b] = tok;
-      a.cur_pos[b] += 1;
-      a.ctx_len[b] += 1;
+      a.cur_pos[b] = pos + 1;
+      a.ctx_len[b] = ctx + 1;
     }
   }
+  if (stop || !a.emb_tab) return;
+  // start of the next step for this row: h = emb[tok] + alpha * pe[pos + 1]; xp = pack(LN(h))   (dec_embed_ln_pack)
+  f32x4 hv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cc = (lane + 64 * i) * 4;
+    hv[i] = *reinterpret_cast<const f32x4*>(a.emb_tab + (long)tok * D_MODEL + cc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) hv[i][q] = __fadd_rn(hv[i][q], __fmul_rn(alpha, pe4[i][q]));
+    *reinterpret_cast<f32x4*>(a.emb_h + (long)b * D_MODEL + cc) = hv[i];
+  }
+  ln_pack_row(hv, b, gg, be, a.emb_xp);
 }
 
 void launch_dec_sample(const SampleArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(dec_sample_kernel, dim3(a.batch), dim3(64), 0, s, a);
+}
+
+// best_of beams (models/vallex.py:525-527 repeats the prompt N times and prefills N times): the prefill ran ONCE, on row 0;
+// copy its L cached K/V rows of every (layer, head) to rows 1 .. beams-1.  grid = (head, beam-1, 2 * layers), 256 threads.
+__global__ __launch_bounds__(256) void beam_kv_broadcast_kernel(float* __restrict__ kc, float* __restrict__ vc, long cache_layer,
+                                                                int Tmax, int L) {
+  const int h = blockIdx.x, beam = blockIdx.y + 1, l = blockIdx.z >> 1;
+  float* base = ((blockIdx.z & 1) ? vc : kc) + (long)l * cache_layer;
+  const f32x4* src = reinterpret_cast<const f32x4*>(base + (long)h * Tmax * D_HEAD);
+  f32x4* dst = reinterpret_cast<f32x4*>(base + ((long)beam * N_HEAD + h) * Tmax * D_HEAD);
+  for (int i = threadIdx.x; i < L * (D_HEAD / 4); i += 256) dst[i] = src[i];
+}
+
+void launch_beam_kv_broadcast(float* kc, float* vc, long cache_layer, int layers, int Tmax, int L, int beams, hipStream_t s) {
+  if (beams <= 1 || L <= 0) return;
+  hipLaunchKernelGGL(beam_kv_broadcast_kernel, dim3(N_HEAD, beams - 1, 2 * layers), dim3(256), 0, s, kc, vc, cache_layer, Tmax, L);
 }
 
 // teacher forcing (tests): commit a caller-chosen token exactly like dec_sample would

@@ -30,6 +30,7 @@ struct Tensor {
 struct LayerW {
   const float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b, *n1_w, *n1_b, *n2_w, *n2_b;
   float *in_wp = nullptr, *out_wp = nullptr, *l1_wp = nullptr, *l2_wp = nullptr;   // packed decode images (AR only)
+  float* out_wh = nullptr;                                                         // head-major W_o (fused out_proj in dec_attn)
   unsigned short *in_w3 = nullptr, *out_w3 = nullptr, *l1_w3 = nullptr, *l2_w3 = nullptr;   // 3 bf16 planes [3][N][K]
 };
 
@@ -87,11 +88,13 @@ struct vx_ctx {
   // decode arena
   float *kc = nullptr, *vc = nullptr;      // [NL][mbr*16][Tmax][64]
   float *dh = nullptr, *xp = nullptr, *xp_att = nullptr, *xp4 = nullptr;
-  float *p_qkv = nullptr, *p_o = nullptr, *p_logits = nullptr, *part_o = nullptr, *part_ml = nullptr;
+  float *p_qkv = nullptr, *p_o = nullptr, *p_oh = nullptr, *p_logits = nullptr, *part_o = nullptr, *part_ml = nullptr;
+  bool balance_rows = true;        // dec_attn launch order pairs long with short contexts per CU (VX_BALANCE_ROWS=0: batch order)
+  bool fuse_out = true;            // out_proj folded into dec_attn when nsplit == 1 (VX_FUSE_OUT=0: separate skinny GEMM)
   float *d_logits = nullptr, *d_uniforms = nullptr, *sum_logp = nullptr;
   long uniforms_cap = 0;
   int *cur_tok = nullptr, *cur_pos = nullptr, *ctx_len = nullptr, *n_gen = nullptr, *active = nullptr,
-      *text_len = nullptr, *gen = nullptr, *force_tok = nullptr, *n_active = nullptr;
+      *text_len = nullptr, *gen = nullptr, *force_tok = nullptr, *n_active = nullptr, *row_order = nullptr;
   int gen_stride = 0;
   int cur_batch = 0;
   int nsplit = 1;
@@ -319,8 +322,12 @@ int check_batch(vx_ctx* c, const vx_batch* b, int max_rows) {
 }
 
 // ---- AR prefill (models/vallex.py:497-562, first ar_decoder.infer call) ------------------------------------
-int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb) {
+// beams > 1 (nb must be 1): best_of.  The reference repeats the prompt N times and runs N identical prefills
+// (models/vallex.py:525-527); here the ONE row is prefilled once and its KV cache, residual row and logits are copied to
+// N decode rows, which then sample independently.
+int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
   const int NL = c->NL;
+  const int nrows = beams > 1 ? beams : nb;          // decode rows after this call
   std::vector<int> seq_off(nb), seq_len(nb), S_(nb), dst_t, id_t, lang_t, pos_t, dst_a, id_a, pos_a, row_b, row_t;
   long M = 0;
   int max_len = 0;
@@ -349,21 +356,37 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb) {
              o_lt = mb.add(lang_t), o_pt = mb.add(pos_t), o_da = mb.add(dst_a), o_ia = mb.add(id_a), o_pa = mb.add(pos_a),
              o_rb = mb.add(row_b), o_rt = mb.add(row_t);
   // decode state
-  std::vector<int> st_pos(nb), st_ctx(nb), st_zero(nb, 0), st_one(nb, 1), st_S(nb);
-  for (int i = 0; i < nb; ++i) { st_pos[i] = b->prompt_lens[r0 + i]; st_ctx[i] = seq_len[i]; st_S[i] = S_[i]; }
-  const long o_sp = mb.add(st_pos), o_sc = mb.add(st_ctx), o_z = mb.add(st_zero), o_1 = mb.add(st_one), o_sS = mb.add(st_S);
+  std::vector<int> st_pos(nrows), st_ctx(nrows), st_zero(nrows, 0), st_one(nrows, 1), st_S(nrows);
+  for (int i = 0; i < nrows; ++i) {
+    const int j = beams > 1 ? 0 : i;
+    st_pos[i] = b->prompt_lens[r0 + j]; st_ctx[i] = seq_len[j]; st_S[i] = S_[j];
+  }
+  // dec_attn launch order (decode.hip): rows by context length, the longest ceil(nb/2) first (descending), then the rest
+  // ascending, so launch slots y and y + nb/2 -- which share a CU -- hold a long and a short context.  The order of the
+  // contexts never changes during generation (every active row grows by one per step).
+  std::vector<int> by_len(nrows), st_ord(nrows);
+  for (int i = 0; i < nrows; ++i) by_len[i] = i;
+  std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int b2) { return st_ctx[a] > st_ctx[b2]; });
+  {
+    const int first = (nrows + 1) / 2;
+    for (int y = 0; y < first; ++y) st_ord[y] = by_len[y];
+    for (int y = first; y < nrows; ++y) st_ord[y] = by_len[nrows - 1 - (y - first)];
+  }
+  const long o_sp = mb.add(st_pos), o_sc = mb.add(st_ctx), o_z = mb.add(st_zero), o_1 = mb.add(st_one), o_sS = mb.add(st_S),
+             o_ord = mb.add(st_ord);
   if (int e = upload_meta(c)) return e;
-  const size_t ib = nb * sizeof(int);
+  const size_t ib = nrows * sizeof(int);
   HIPCHK(hipMemcpyAsync(c->cur_pos, mb.dev(o_sp), ib, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->ctx_len, mb.dev(o_sc), ib, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->n_gen, mb.dev(o_z), ib, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->cur_tok, mb.dev(o_z), ib, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->active, mb.dev(o_1), ib, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->text_len, mb.dev(o_sS), ib, hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(c->n_active, &nb, sizeof(int), hipMemcpyHostToDevice, c->stream));
-  c->cur_batch = nb;
+  HIPCHK(hipMemcpyAsync(c->row_order, mb.dev(o_ord), ib, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->n_active, &nrows, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  c->cur_batch = nrows;
   // enough (row, head, split) 8-wave workgroups to put >= 2 on every CU; one split (no combine launch) from 32 rows up
-  c->nsplit = std::max(1, std::min(16, 512 / (nb * N_HEAD)));
+  c->nsplit = std::max(1, std::min(16, 512 / (nrows * N_HEAD)));
 
   launch_embed_rows(c->fx, mb.dev(o_dt), W(c, "ar_text_embedding.word_embeddings.weight"), mb.dev(o_it),
                     W(c, "ar_language_embedding.word_embeddings.weight"), mb.dev(o_lt), W(c, "ar_text_position.alpha"),
@@ -393,6 +416,16 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb) {
   launch_dec_reduce_ln_pack(nullptr, 0, D_MODEL, nullptr, c->dh, nullptr, W(c, "ar_decoder.norm.weight"),
                             W(c, "ar_decoder.norm.bias"), c->xp, nb, c->stream);
   launch_skinny_gemm(c->pred_wp, c->xp, c->p_logits, PRED_NPAD, D_MODEL, SK_PRED, nullptr, c->stream);
+  if (beams > 1) {
+    launch_beam_kv_broadcast(c->kc, c->vc, (long)cache_layer, NL, c->Tmax, seq_len[0], beams, c->stream);
+    for (int i = 1; i < beams; ++i) {
+      HIPCHK(hipMemcpyAsync(c->dh + (size_t)i * D_MODEL, c->dh, D_MODEL * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+      for (int ks = 0; ks < SK_PRED; ++ks)
+        HIPCHK(hipMemcpyAsync(c->p_logits + ((size_t)ks * MB + i) * PRED_NPAD, c->p_logits + (size_t)ks * MB * PRED_NPAD,
+                              PRED_NPAD * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->h_L.assign(beams, seq_len[0]);
+  }
   return VX_OK;
 }
 
@@ -411,6 +444,10 @@ SampleArgs make_sample_args(vx_ctx* c, const vx_sampling* s, int commit, float* 
   a.text_len = c->text_len; a.gen = c->gen; a.gen_stride = c->gen_stride; a.logits_out = logits_out;
   a.sum_logp = (s && s->best_of > 1) ? c->sum_logp : nullptr;
   a.batch = c->cur_batch;
+  if (commit) {      // the sampler also embeds the committed token and applies norm1 of layer 0 (start of the next step)
+    a.emb_tab = W(c, "ar_audio_embedding.word_embeddings.weight"); a.emb_alpha = W(c, "ar_audio_position.alpha");
+    a.pe = c->pe; a.ln_g = c->ar[0].n1_w; a.ln_b = c->ar[0].n1_b; a.emb_h = c->dh; a.emb_xp = c->xp;
+  }
   return a;
 }
 
@@ -419,19 +456,28 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
   const int nb = c->cur_batch, NL = c->NL;
   hipStream_t st = c->stream;
   const size_t cache_layer = (size_t)c->mbr * N_HEAD * c->Tmax * D_HEAD;
-  launch_dec_embed_ln_pack(c->cur_tok, c->cur_pos, W(c, "ar_audio_embedding.word_embeddings.weight"),
-                           W(c, "ar_audio_position.alpha"), c->pe, c->dh, c->ar[0].n1_w, c->ar[0].n1_b, c->xp, nb, st);
+  // sampling mode: the previous dec_sample already embedded the token and applied norm1 of layer 0; the teacher-forced
+  // mode (sa == null, vx_ar_step) has to do it here
+  if (!sa)
+    launch_dec_embed_ln_pack(c->cur_tok, c->cur_pos, W(c, "ar_audio_embedding.word_embeddings.weight"),
+                             W(c, "ar_audio_position.alpha"), c->pe, c->dh, c->ar[0].n1_w, c->ar[0].n1_b, c->xp, nb, st);
   for (int l = 0; l < NL; ++l) {
     const LayerW& L = c->ar[l];
     { ProfScope ps(c, 1); launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, c->n_active, st); }
+    const bool fused = c->fuse_out && c->nsplit == 1;
     {
       ProfScope ps(c, 0);
       launch_dec_attn(c->p_qkv, SK_QKV, L.in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax, c->ctx_len,
-                      c->active, c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, st);
+                      c->active, c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, fused ? L.out_wh : nullptr, c->p_oh,
+                      c->balance_rows ? c->row_order : nullptr, st);
     }
-    if (c->nsplit > 1) launch_dec_attn_combine(c->part_o, c->part_ml, c->nsplit, c->active, c->xp_att, nb, st);
-    { ProfScope ps(c, 1); launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, c->n_active, st); }
-    launch_dec_reduce_ln_pack(c->p_o, SK_OUT, D_MODEL, L.out_b, c->dh, c->dh, L.n2_w, L.n2_b, c->xp, nb, st);
+    if (fused) {
+      launch_dec_reduce_ln_pack(c->p_oh, N_HEAD, D_MODEL, L.out_b, c->dh, c->dh, L.n2_w, L.n2_b, c->xp, nb, st);
+    } else {
+      if (c->nsplit > 1) launch_dec_attn_combine(c->part_o, c->part_ml, c->nsplit, c->active, c->xp_att, nb, st);
+      { ProfScope ps(c, 1); launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, c->n_active, st); }
+      launch_dec_reduce_ln_pack(c->p_o, SK_OUT, D_MODEL, L.out_b, c->dh, c->dh, L.n2_w, L.n2_b, c->xp, nb, st);
+    }
     { ProfScope ps(c, 1); launch_skinny16_relu_pack(L.l1_wp, c->xp, L.l1_b, c->xp4, D_FF, D_MODEL, c->n_active, st); }
     { ProfScope ps(c, 1); launch_skinny_gemm(L.l2_wp, c->xp4, c->p_o, D_MODEL, D_FF, SK_L2, c->n_active, st); }
     const float* ng = (l + 1 < NL) ? c->ar[l + 1].n1_w : W(c, "ar_decoder.norm.weight");
@@ -464,8 +510,10 @@ int ar_step_run(vx_ctx* c, const SampleArgs* sa, const std::string& sig) {
 
 // ---- AR generation for one micro-batch -----------------------------------------------------------------------
 int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int nb, std::vector<int>& n_gen,
-                std::vector<int>& gen) {
-  if (int e = ar_prefill(c, b, r0, nb)) return e;
+                std::vector<int>& gen, int beams = 1) {
+  if (int e = ar_prefill(c, b, r0, nb, beams)) return e;
+  const int ub = beams > 1 ? beams : b->batch;       // columns of the caller's uniforms: [steps][batch] or [steps][best_of]
+  if (beams > 1) nb = beams;
   if (s->uniforms) {
     // slice [steps][batch] -> [steps][nb] for this micro-batch
     // only the first gen_stride + 1 draws can ever be consumed (one per generated frame + the terminating sample)
@@ -473,7 +521,7 @@ int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int 
     if (steps * nb > c->uniforms_cap) FAIL(VX_EINVAL, "too many uniforms (%ld steps)", steps);
     std::vector<float> u((size_t)steps * nb);
     for (long t = 0; t < steps; ++t)
-      for (int i = 0; i < nb; ++i) u[t * nb + i] = s->uniforms[t * b->batch + r0 + i];
+      for (int i = 0; i < nb; ++i) u[t * nb + i] = s->uniforms[t * ub + r0 + i];
     HIPCHK(hipMemcpyAsync(c->d_uniforms, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
   }
@@ -809,6 +857,9 @@ int vx_finalize_weights(vx_ctx* c) {
   if ((e = dev_alloc(c, &c->xp4, (size_t)2 * MB * f))) return e;   // linear1's two split-K slabs, packed image
   if ((e = dev_alloc(c, &c->p_qkv, (size_t)SK_QKV * MB * 3 * d))) return e;
   if ((e = dev_alloc(c, &c->p_o, (size_t)std::max(SK_OUT, SK_L2) * MB * d))) return e;
+  if ((e = dev_alloc(c, &c->p_oh, (size_t)N_HEAD * MB * d))) return e;
+  if (const char* ev = getenv("VX_FUSE_OUT")) c->fuse_out = !(ev[0] == '0');
+  if (const char* ev = getenv("VX_BALANCE_ROWS")) c->balance_rows = !(ev[0] == '0');
   if ((e = dev_alloc(c, &c->p_logits, (size_t)SK_PRED * MB * PRED_NPAD))) return e;
   if ((e = dev_alloc(c, &c->part_o, (size_t)MB * N_HEAD * 16 * D_HEAD))) return e;
   if ((e = dev_alloc(c, &c->part_ml, (size_t)MB * N_HEAD * 16 * 2))) return e;
@@ -816,7 +867,8 @@ int vx_finalize_weights(vx_ctx* c) {
   if ((e = dev_alloc(c, &c->sum_logp, (size_t)MB))) return e;
   c->uniforms_cap = (long)(c->cfg.max_new + 2) * MB;
   if ((e = dev_alloc(c, &c->d_uniforms, (size_t)c->uniforms_cap))) return e;
-  for (int** p : {&c->cur_tok, &c->cur_pos, &c->ctx_len, &c->n_gen, &c->active, &c->text_len, &c->force_tok, &c->n_active})
+  for (int** p : {&c->cur_tok, &c->cur_pos, &c->ctx_len, &c->n_gen, &c->active, &c->text_len, &c->force_tok, &c->n_active,
+                  &c->row_order})
     if ((e = dev_alloc(c, p, MB))) return e;
   if ((e = dev_alloc(c, &c->gen, (size_t)MB * c->gen_stride))) return e;
 
@@ -873,6 +925,8 @@ int vx_finalize_weights(vx_ctx* c) {
     LayerW& L = c->ar[l];
     if ((e = pack(c, L.in_w, 3 * d, d, 3 * d, &L.in_wp))) return e;
     if ((e = pack(c, L.out_w, d, d, d, &L.out_wp))) return e;
+    if ((e = dev_alloc(c, &L.out_wh, (size_t)d * d, false))) return e;
+    launch_pack_wo_heads(L.out_w, L.out_wh, c->stream);
     if ((e = dev_alloc(c, &L.l1_wp, (size_t)f * d, false))) return e;       // 16-row tile image (fused linear1)
     launch_pack_weight16(L.l1_w, f, d, L.l1_wp, c->stream);
     if ((e = pack(c, L.l2_w, d, f, d, &L.l2_wp))) return e;
@@ -1281,16 +1335,9 @@ int vx_infer(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int64_t* out_co
     if (b->batch != 1) FAIL(VX_EINVAL, "best_of > 1 needs batch == 1 (models/vallex.py:491)");
     const int N = s->best_of;
     if (N > c->mbr) FAIL(VX_EINVAL, "best_of %d exceeds the micro-batch (%d)", N, c->mbr);
-    const int S = b->text_lens[0], Tp = b->prompt_lens[0];
-    std::vector<int> ids((size_t)N * S), lg((size_t)N * S), tl(N, S), pc((size_t)N * std::max(Tp, 1) * N_Q, 0), pl(N, Tp);
-    for (int i = 0; i < N; ++i) {
-      memcpy(&ids[(size_t)i * S], b->text_ids, S * sizeof(int));
-      memcpy(&lg[(size_t)i * S], b->text_lang, S * sizeof(int));
-      if (Tp) memcpy(&pc[(size_t)i * Tp * N_Q], b->prompt_codes, (size_t)Tp * N_Q * sizeof(int));
-    }
-    vx_batch rb{(uint32_t)sizeof(vx_batch), N, ids.data(), lg.data(), S, tl.data(), pc.data(), std::max(Tp, 1), pl.data()};
+    const int Tp = b->prompt_lens[0];
     std::vector<int> n_gen, gen, oc;
-    if (int e = ar_generate(c, &rb, s, 0, N, n_gen, gen)) return e;
+    if (int e = ar_generate(c, b, s, 0, 1, n_gen, gen, N)) return e;     // ONE prefill, N decode rows
     std::vector<float> slp(N);
     HIPCHK(hipMemcpy(slp.data(), c->sum_logp, N * sizeof(float), hipMemcpyDeviceToHost));
     int best = 0, worst = 0;
@@ -1693,6 +1740,7 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
       ctx[i] = std::min(c->h_L[i] + std::max(gen_offset, 1), c->Tmax - 1);
       bytes += (double)ctx[i] * 2.0 * D_MODEL * 4.0;
     }
+    if (c->fuse_out && c->nsplit == 1) bytes += (double)D_MODEL * D_MODEL * 4.0;     // + W_o, streamed once (fused out_proj)
     HIPCHK(hipMemcpyAsync(c->ctx_len, ctx.data(), nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->active, one.data(), nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1701,8 +1749,10 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
     const size_t cache_layer = (size_t)c->mbr * N_HEAD * c->Tmax * D_HEAD;
     auto attn_l = [&](int r) {
       const int l = r % c->NL;
+      const bool fused = c->fuse_out && c->nsplit == 1;
       launch_dec_attn(c->p_qkv, SK_QKV, c->ar[l].in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax, c->ctx_len,
-                      c->active, c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, c->stream);
+                      c->active, c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, fused ? c->ar[l].out_wh : nullptr, c->p_oh,
+                      c->balance_rows ? c->row_order : nullptr, c->stream);
     };
     for (int w = 0; w < 3; ++w) attn_l(w);
     HIPCHK(hipEventRecord(e0, c->stream));
@@ -1771,7 +1821,7 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
   GemmArgs g0{};
   g0.A = A; g0.lda = K; g0.W = Wt; g0.ldw = K; g0.C = C0; g0.ldc = N; g0.M = M; g0.N = N; g0.K = K; g0.act = ACT_NONE;
   launch_gemm_f32(g0, c->stream);
-  if (kernel == 6) {                                             // fp16 head / scaled tail planes
+  if (kernel == 6 || kernel >= 61) {                             // fp16 head / scaled tail planes
     launch_split2h(A, K, M, K, nullptr, A3, (long)M * K, nullptr, c->stream);
     launch_split2h(Wt, K, N, K, nullptr, W3, (long)N * K, nullptr, c->stream);
   } else {
@@ -1789,6 +1839,7 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
     else if (kernel == 2) launch_gemm_bf16x3_dma(gx, c->stream);
     else if (kernel == 6) launch_gemm_f16x2(gx, c->stream);
 #ifdef VX_DEV_PROBES
+    else if (kernel >= 61) launch_gemm_f16x2_probe(gx, kernel - 60, c->stream);         // 61-64: probes of the f16x2 kernel
     else if (kernel >= 21) launch_gemm_bf16x3_dma_probe(gx, kernel - 20, c->stream);   // 21-24: probes of the DMA kernel
     else launch_gemm_bf16x3_probe(gx, kernel - 10, c->stream);      // 11 / 12 / 13: timing probes
 #endif

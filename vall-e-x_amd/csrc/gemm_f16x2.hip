@@ -77,6 +77,9 @@ void launch_split2h(const float* x, int ldx, long rows, int K, const int* gather
                      gather, planes, plane_stride, range_flag);
 }
 
+// V = 0 product kernel.  Timing probes (VX_DEV_PROBES builds, tools/gemm_bench.py; results meaningless): V = 1 no DMA after the
+// first two tiles; V = 2 no MFMAs; V = 3 fragments read once; V = 4 no barriers / vmcnt waits (racy).
+template <int V>
 __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
   __shared__ __attribute__((aligned(1024))) unsigned char stage0[HSTAGE];
   __shared__ __attribute__((aligned(1024))) unsigned char stage1[HSTAGE];
@@ -151,6 +154,14 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
     // transposed product (A operand = W rows); per (i, jn): tail x head, head x tail into acc_t, head x head into acc_h
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      if (V == 2) {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+          acc_t[i][jn][0] += (float)w[1][jn][0] * (float)a[i][0][0] + (float)w[0][jn][1] * (float)a[i][1][1];
+          acc_h[i][jn][0] += (float)w[0][jn][0] * (float)a[i][0][0];
+        }
+        continue;
+      }
 #pragma unroll
       for (int jn = 0; jn < 2; ++jn) acc_t[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][jn], a[i][0], acc_t[i][jn], 0, 0, 0);
 #pragma unroll
@@ -159,27 +170,33 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
       for (int jn = 0; jn < 2; ++jn) acc_t[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][jn], a[i][1], acc_t[i][jn], 0, 0, 0);
     }
   };
-  auto ktile = [&](const unsigned char* stage, unsigned char* other, int kt_next, bool more) {
-    f16x8 w0[2][2], a0[2][2], w1[2][2], a1[2][2];
-    if (more) dma(other, kt_next);
-    frags(stage, 0, w0, a0);
-    frags(stage, 1, w1, a1);
+  f16x8 w0[2][2], a0[2][2], w1[2][2], a1[2][2];
+  auto ktile = [&](const unsigned char* stage, unsigned char* other, int kt_next, bool more, bool first) {
+    if (more && (V != 1 || kt_next < 2)) dma(other, kt_next);
+    if (V != 3 || first) {
+      frags(stage, 0, w0, a0);
+      frags(stage, 1, w1, a1);
+    }
     mfmas(w0, a0);
     mfmas(w1, a1);
+  };
+  auto rendezvous = [&]() {
+    if (V == 4) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   };
 
   const int nk = g.K / HK;
   dma(stage0, 0);
   for (int kt = 0; kt < nk; kt += 2) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    ktile(stage0, stage1, kt + 1, kt + 1 < nk);
+    rendezvous();
+    ktile(stage0, stage1, kt + 1, kt + 1 < nk, kt == 0);
     if (kt + 1 < nk) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      ktile(stage1, stage0, kt + 2, kt + 2 < nk);
+      rendezvous();
+      ktile(stage1, stage0, kt + 2, kt + 2 < nk, false);
     }
   }
+  if (V == 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
 
   // epilogue: C = heads + cross / 2048 (+ bias, activation, residual as in the bf16x3 kernels)
 #pragma unroll
@@ -218,7 +235,19 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
 void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s) {
   const int tiles = ((g.M + HM - 1) / HM) * ((g.N + HN - 1) / HN);
   if (tiles <= 0) return;
-  hipLaunchKernelGGL(gemm_f16x2_kernel, dim3(tiles), dim3(512), 0, s, g);
+  hipLaunchKernelGGL(gemm_f16x2_kernel<0>, dim3(tiles), dim3(512), 0, s, g);
 }
+
+#ifdef VX_DEV_PROBES   // timing probes: tools-only build (vall-e-x_amd/_build.py --dev), never in the product library
+void launch_gemm_f16x2_probe(const GemmX3Args& g, int variant, hipStream_t s) {
+  const int tiles = ((g.M + HM - 1) / HM) * ((g.N + HN - 1) / HN);
+  if (tiles <= 0) return;
+  const dim3 grid(tiles), block(512);
+  if (variant == 1) hipLaunchKernelGGL(gemm_f16x2_kernel<1>, grid, block, 0, s, g);
+  else if (variant == 2) hipLaunchKernelGGL(gemm_f16x2_kernel<2>, grid, block, 0, s, g);
+  else if (variant == 3) hipLaunchKernelGGL(gemm_f16x2_kernel<3>, grid, block, 0, s, g);
+  else hipLaunchKernelGGL(gemm_f16x2_kernel<4>, grid, block, 0, s, g);
+}
+#endif
 
 }  // namespace vx

@@ -60,6 +60,7 @@ void launch_split3(const float* x, int ldx, long rows, int K, const int* gather,
 #ifdef VX_DEV_PROBES
 void launch_gemm_bf16x3_probe(const GemmX3Args& g, int variant, hipStream_t s);
 void launch_gemm_bf16x3_dma_probe(const GemmX3Args& g, int variant, hipStream_t s);
+void launch_gemm_f16x2_probe(const GemmX3Args& g, int variant, hipStream_t s);
 #endif
 
 // ---- row-wise ops (rows.hip) --------------------------------------------------------------------
@@ -118,9 +119,11 @@ void launch_skinny16_relu_pack(const float* W16, const float* xp, const float* b
 void launch_dec_embed_ln_pack(const int* tok, const int* pos, const float* tab, const float* alpha, const float* pe,
                               float* h, const float* g, const float* b, float* xp, int batch, hipStream_t s);
 // one-token attention over the cache, per (b, head, split); appends the new k/v (from the QKV partials).
+// wo_heads != null and nsplit == 1: out_proj fused into the epilogue, per-head partial slabs out_heads[h][MB][1024]
 void launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias, float* kc, float* vc, int Tmax,
                      const int* ctx_len, const int* active, float* xp_out, float* part_o, float* part_ml, int nsplit,
-                     int batch, hipStream_t s);
+                     int batch, const float* wo_heads, float* out_heads, const int* row_order, hipStream_t s);
+void launch_pack_wo_heads(const float* W, float* out, hipStream_t s);
 void launch_dec_attn_combine(const float* part_o, const float* part_ml, int nsplit, const int* active, float* xp_out,
                              int batch, hipStream_t s);
 struct SampleArgs {
@@ -135,8 +138,13 @@ struct SampleArgs {
   float* logits_out;                               // optional [MB][1025] copy of the reduced logits
   float* sum_logp;                                 // optional [MB] running sum of log p(pick) per row (beam selection)
   int batch;
+  // optional fused start of the next step (dec_embed_ln_pack for the committed token); emb_tab == null: off
+  const float* emb_tab; const float* emb_alpha; const float* pe; const float* ln_g; const float* ln_b;
+  float* emb_h; float* emb_xp;
 };
 void launch_dec_sample(const SampleArgs& a, hipStream_t s);
+// best_of: copy row 0's prefilled K/V (L rows per head, every layer) to rows 1 .. beams-1
+void launch_beam_kv_broadcast(float* kc, float* vc, long cache_layer, int layers, int Tmax, int L, int beams, hipStream_t s);
 void launch_dec_force_token(const int* tok, int* cur_tok, int* cur_pos, int* ctx_len, int* n_gen, int* gen,
                             int gen_stride, const int* active, int batch, hipStream_t s);
 
