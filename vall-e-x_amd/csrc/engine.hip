@@ -248,10 +248,11 @@ void proj(vx_ctx* c, const float* A, int lda, const float* Wf, const unsigned sh
     gemm(c, A, lda, Wf, K, bias, resid, ldr, nullptr, C, ldc, M, N, K, act, gather);
     return;
   }
-  if (c->gemm_mode == 0) launch_split2h(A, lda, M, K, gather, c->fa3, (long)M * K, c->range_flag, c->stream);
-  else launch_split3(A, lda, M, K, gather, c->fa3, (long)M * K, c->stream);
+  const long a_plane = c->gemm_mode == 0 ? h2_plane(M, K, H2_TILE_A) : (long)M * K;
+  if (c->gemm_mode == 0) launch_split2h(A, lda, M, K, gather, c->fa3, a_plane, H2_TILE_A, c->range_flag, c->stream);
+  else launch_split3(A, lda, M, K, gather, c->fa3, a_plane, c->stream);
   GemmX3Args g{};
-  g.A = c->fa3; g.a_plane = (long)M * K; g.W = W3; g.w_plane = (long)N * K; g.bias = bias; g.resid = resid; g.ldr = ldr;
+  g.A = c->fa3; g.a_plane = a_plane; g.W = W3; g.w_plane = c->gemm_mode == 0 ? h2_plane(N, K, H2_TILE_W) : (long)N * K; g.bias = bias; g.resid = resid; g.ldr = ldr;
   g.colscale = nullptr; g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.act = act;
   ProfScope ps(c, 2);
   if (c->prof_on) c->prof[2].bytes += 2.0 * (double)M * N * K;
@@ -902,8 +903,8 @@ int vx_finalize_weights(vx_ctx* c) {
   if (c->gemm_mode != 2) {
     const int P = c->gemm_mode == 0 ? 2 : 3;
     auto split_w = [&](const float* Wt, int N, int K, unsigned short** out) -> int {
-      if (int e2 = dev_alloc(c, out, (size_t)P * N * K, false)) return e2;
-      if (c->gemm_mode == 0) launch_split2h(Wt, K, N, K, nullptr, *out, (long)N * K, c->range_flag, c->stream);
+      if (int e2 = dev_alloc(c, out, (size_t)P * h2_plane(N, K, H2_TILE_W), false)) return e2;
+      if (c->gemm_mode == 0) launch_split2h(Wt, K, N, K, nullptr, *out, h2_plane(N, K, H2_TILE_W), H2_TILE_W, c->range_flag, c->stream);
       else launch_split3(Wt, K, N, K, nullptr, *out, (long)N * K, c->stream);
       return VX_OK;
     };
@@ -917,7 +918,7 @@ int vx_finalize_weights(vx_ctx* c) {
       }
     for (int j = 0; j < N_Q - 1; ++j)
       if ((e = split_w(W(c, "nar_predict_layers." + std::to_string(j) + ".weight"), AUDIO_VOCAB, d, &c->pred_w3[j]))) return e;
-    if ((e = dev_alloc(c, &c->fa3, (size_t)P * (c->Mmax + 128) * f, false))) return e;
+    if ((e = dev_alloc(c, &c->fa3, (size_t)P * (c->Mmax + 256) * f))) return e;       // zeroed: the pad rows of a last tile are read
   }
 
   // ---- packed decode images of the AR stack ----
@@ -1795,7 +1796,8 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
                   double* max_abs_diff) {
   if (!c || M <= 0 || N <= 0 || K <= 0 || K % 32 || N % 4 || reps <= 0 || !avg_us || !max_abs_diff) return VX_EINVAL;
 #ifndef VX_DEV_PROBES
-  if (kernel != 0 && kernel != 1 && kernel != 2 && kernel != 6) FAIL(VX_EINVAL, "kernel must be 0, 1, 2 or 6 (probes need a VX_DEV_PROBES build)");
+  if (kernel != 0 && kernel != 1 && kernel != 2 && kernel != 6)
+    FAIL(VX_EINVAL, "kernel must be 0, 1, 2 or 6 (probes need a VX_DEV_PROBES build)");
 #endif
   HIPCHK(hipSetDevice(c->dev));
   float *A = nullptr, *Wt = nullptr, *C0 = nullptr, *C1 = nullptr;
@@ -1807,8 +1809,10 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
   TRY(hipMalloc((void**)&Wt, (size_t)N * K * 4));
   TRY(hipMalloc((void**)&C0, (size_t)M * N * 4));
   TRY(hipMalloc((void**)&C1, (size_t)M * N * 4));
-  TRY(hipMalloc((void**)&A3, (size_t)3 * M * K * 2));
-  TRY(hipMalloc((void**)&W3, (size_t)3 * N * K * 2));
+  TRY(hipMalloc((void**)&A3, (size_t)3 * h2_plane(M, K, H2_TILE_A) * 2));
+  TRY(hipMalloc((void**)&W3, (size_t)3 * h2_plane(N, K, H2_TILE_W) * 2));
+  TRY(hipMemset(A3, 0, (size_t)3 * h2_plane(M, K, H2_TILE_A) * 2));
+  TRY(hipMemset(W3, 0, (size_t)3 * h2_plane(N, K, H2_TILE_W) * 2));
   {
     std::vector<float> h((size_t)std::max(M, N) * K);
     unsigned long long st = 0x9E3779B97F4A7C15ull;
@@ -1822,14 +1826,15 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
   g0.A = A; g0.lda = K; g0.W = Wt; g0.ldw = K; g0.C = C0; g0.ldc = N; g0.M = M; g0.N = N; g0.K = K; g0.act = ACT_NONE;
   launch_gemm_f32(g0, c->stream);
   if (kernel == 6 || kernel >= 61) {                             // fp16 head / scaled tail planes
-    launch_split2h(A, K, M, K, nullptr, A3, (long)M * K, nullptr, c->stream);
-    launch_split2h(Wt, K, N, K, nullptr, W3, (long)N * K, nullptr, c->stream);
+    launch_split2h(A, K, M, K, nullptr, A3, h2_plane(M, K, H2_TILE_A), H2_TILE_A, nullptr, c->stream);
+    launch_split2h(Wt, K, N, K, nullptr, W3, h2_plane(N, K, H2_TILE_W), H2_TILE_W, nullptr, c->stream);
   } else {
     launch_split3(A, K, M, K, nullptr, A3, (long)M * K, c->stream);
     launch_split3(Wt, K, N, K, nullptr, W3, (long)N * K, c->stream);
   }
   GemmX3Args gx{};
-  gx.A = A3; gx.a_plane = (long)M * K; gx.W = W3; gx.w_plane = (long)N * K; gx.C = C1; gx.ldc = N; gx.M = M; gx.N = N; gx.K = K;
+  const bool h2 = kernel == 6 || kernel >= 61;
+  gx.A = A3; gx.a_plane = h2 ? h2_plane(M, K, H2_TILE_A) : (long)M * K; gx.W = W3; gx.w_plane = h2 ? h2_plane(N, K, H2_TILE_W) : (long)N * K; gx.C = C1; gx.ldc = N; gx.M = M; gx.N = N; gx.K = K;
   gx.act = ACT_NONE;
   GemmArgs g1 = g0;
   g1.C = C1;

@@ -36,15 +36,19 @@ typedef void __attribute__((address_space(3)))* lptr_t;
 
 }  // namespace
 
-// x[rows][K] fp32 (row r read at gather ? gather[r] : r) -> planes[p][K/32][rows][32] fp16 (K-tile-major like split3_kernel),
-// p = 0 head, 1 tail * 2048
+// x[rows][K] fp32 (row r read at gather ? gather[r] : r) -> planes[p][rows/TR][K/32][TR][32] fp16, p = 0 head, 1 tail * 2048.
+// TILE-major: the TR = 256 (activations) or 128 (weights) rows x K panel that ONE workgroup of the GEMM streams is one
+// contiguous run (TR * K * 2 B per plane), walked linearly by its K loop -- instead of 16 KiB pieces 64 B * rows apart
+// (K-tile-major, the bf16x3 layout), i.e. one DRAM page / TLB entry per K tile and workgroup.  Rows past `rows` in the last
+// tile are never written (the GEMM reads them as garbage into accumulator rows it never stores).
 // range_flag (optional): set to 1 if any |x| does not fit fp16 (>= 65504 or non-finite) -- the engine turns that into an error
 // instead of letting an inf head poison the GEMM silently.
 __global__ __launch_bounds__(256) void split2h_kernel(const float* __restrict__ x, int ldx, long rows, int K,
                                                       const int* __restrict__ gather,
-                                                      unsigned short* __restrict__ planes, long plane_stride,
+                                                      unsigned short* __restrict__ planes, long plane_stride, int tile_rows,
                                                       int* __restrict__ range_flag) {
   const long total = (long)(K / 32) * rows * 4;
+  const int nkt = K / 32;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int ch = (int)(i & 3);
     const long rr = i >> 2;
@@ -62,19 +66,21 @@ __global__ __launch_bounds__(256) void split2h_kernel(const float* __restrict__ 
       h[e] = (_Float16)v[e];                                     // RNE
       t[e] = (_Float16)((v[e] - (float)h[e]) * TAIL_SCALE);      // exact difference, exact scaling, rounded once
     }
-    unsigned short* o = planes + i * 8;
+    const long tile = r / tile_rows, rin = r - tile * tile_rows;
+    unsigned short* o = planes + ((tile * nkt + kt) * tile_rows + rin) * 32 + ch * 8;
     *reinterpret_cast<f16x8*>(o) = h;
     *reinterpret_cast<f16x8*>(o + plane_stride) = t;
     if (bad && range_flag) *range_flag = 1;
   }
 }
 
+// plane_stride must be >= roundup(rows, tile_rows) * K elements
 void launch_split2h(const float* x, int ldx, long rows, int K, const int* gather, unsigned short* planes, long plane_stride,
-                    int* range_flag, hipStream_t s) {
+                    int tile_rows, int* range_flag, hipStream_t s) {
   if (rows <= 0) return;
   const long total = rows * (K / 8);
   hipLaunchKernelGGL(split2h_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, x, ldx, rows, K,
-                     gather, planes, plane_stride, range_flag);
+                     gather, planes, plane_stride, tile_rows, range_flag);
 }
 
 // V = 0 product kernel.  Timing probes (VX_DEV_PROBES builds, tools/gemm_bench.py; results meaningless): V = 1 no DMA after the
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
   __shared__ __attribute__((aligned(1024))) unsigned char stage0[HSTAGE];
   __shared__ __attribute__((aligned(1024))) unsigned char stage1[HSTAGE];
 
-  constexpr int GM = 8;
+  constexpr int GM = V == 5 ? 4 : V == 6 ? 16 : V == 7 ? 2 : 8;     // probes 5-7: other XCD-wave shapes (GM x 32/GM tiles)
   const int tiles_m = (g.M + HM - 1) / HM, tiles_n = (g.N + HN - 1) / HN;
   const int nwg = tiles_m * tiles_n;
   int wg = blockIdx.x;
@@ -115,11 +121,10 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
     const int p = isA ? qq >> 4 : qq >> 3, r16 = isA ? qq & 15 : qq & 7;
     const int row = r16 * 16 + (lane >> 2);
     const int ch = (lane & 3) ^ ((lane >> 4) & 3);
-    int grow = (isA ? m0 : n0) + row;
-    const int lim = isA ? g.M : g.N;
-    grow = grow < lim ? grow : lim - 1;
-    src[j] = (isA ? g.A + p * g.a_plane : g.W + p * g.w_plane) + (long)grow * HK + ch * 8;
-    kstep[j] = (long)lim * HK;
+    // tile-major planes: this workgroup's A (W) panel is one contiguous run of K/32 blocks of HM (HN) rows x 32
+    const long tile0 = (V == 8 || V == 9) ? 0 : (long)(isA ? tm : tn) * (g.K / HK) * ((isA ? HM : HN) * HK);   // probes 8/9: every workgroup streams tile 0 (all L2 hits)
+    src[j] = (isA ? g.A + p * g.a_plane : g.W + p * g.w_plane) + tile0 + (long)row * HK + ch * 8;
+    kstep[j] = (long)(isA ? HM : HN) * HK;
     lds_off[j] = (isA ? p * HA_PL : 2 * HA_PL + p * HW_PL) + r16 * 1024;
   }
   auto dma = [&](unsigned char* stage, int kt) {
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
     // transposed product (A operand = W rows); per (i, jn): tail x head, head x tail into acc_t, head x head into acc_h
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (V == 2) {
+      if (V == 2 || V == 9) {
 #pragma unroll
         for (int jn = 0; jn < 2; ++jn) {
           acc_t[i][jn][0] += (float)w[1][jn][0] * (float)a[i][0][0] + (float)w[0][jn][1] * (float)a[i][1][1];
@@ -246,6 +251,11 @@ void launch_gemm_f16x2_probe(const GemmX3Args& g, int variant, hipStream_t s) {
   if (variant == 1) hipLaunchKernelGGL(gemm_f16x2_kernel<1>, grid, block, 0, s, g);
   else if (variant == 2) hipLaunchKernelGGL(gemm_f16x2_kernel<2>, grid, block, 0, s, g);
   else if (variant == 3) hipLaunchKernelGGL(gemm_f16x2_kernel<3>, grid, block, 0, s, g);
+  else if (variant == 5) hipLaunchKernelGGL(gemm_f16x2_kernel<5>, grid, block, 0, s, g);
+  else if (variant == 6) hipLaunchKernelGGL(gemm_f16x2_kernel<6>, grid, block, 0, s, g);
+  else if (variant == 7) hipLaunchKernelGGL(gemm_f16x2_kernel<7>, grid, block, 0, s, g);
+  else if (variant == 8) hipLaunchKernelGGL(gemm_f16x2_kernel<8>, grid, block, 0, s, g);
+  else if (variant == 9) hipLaunchKernelGGL(gemm_f16x2_kernel<9>, grid, block, 0, s, g);
   else hipLaunchKernelGGL(gemm_f16x2_kernel<4>, grid, block, 0, s, g);
 }
 #endif

@@ -40,7 +40,8 @@ void launch_gemm_f32(const GemmArgs& g, hipStream_t s);
 
 // ---- fp32-class GEMMs on the 16-bit matrix cores ----------------------------------------------------------------
 // Operands are pre-split planes, each K-tile-major [K/32][rows][32] 16-bit; same epilogue contract as GemmArgs.  K % 32 == 0.
-//   f16x2  (gemm_f16x2.hip, DEFAULT): 2 planes  x = h + t/2048 (fp16 head + fp16 tail), 3 f16 MFMAs per product block
+//   f16x2  (gemm_f16x2.hip, DEFAULT): 2 planes  x = h + t/2048 (fp16 head + fp16 tail), 3 f16 MFMAs per product block;
+//          its planes are TILE-major (see launch_split2h), not K-tile-major
 //   bf16x3 (gemm_bf16x3*.hip, VX_GEMM_X3=1): 3 bf16 planes x = x1 + x2 + x3, 6 bf16 MFMAs per product block
 struct GemmX3Args {
   const unsigned short* A; long a_plane;   // [P][M][K], plane stride in elements (P = 2 or 3)
@@ -51,8 +52,12 @@ struct GemmX3Args {
   int act;
 };
 void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s);                 // 256 x 128 x 32 tile, async LDS fill, any M
+// f16x2 planes are TILE-major: [rows / tile_rows][K/32][tile_rows][32], tile_rows = 256 (A operand) or 128 (W operand);
+// plane_stride >= roundup(rows, tile_rows) * K.  *range_flag = 1 if some |x| does not fit fp16.
+constexpr int H2_TILE_A = 256, H2_TILE_W = 128;
+inline long h2_plane(long rows, int K, int tile_rows) { return (rows + tile_rows - 1) / tile_rows * tile_rows * (long)K; }
 void launch_split2h(const float* x, int ldx, long rows, int K, const int* gather, unsigned short* planes, long plane_stride,
-                    int* range_flag, hipStream_t s);                        // *range_flag = 1 if some |x| does not fit fp16
+                    int tile_rows, int* range_flag, hipStream_t s);
 void launch_gemm_bf16x3(const GemmX3Args& g, hipStream_t s);                // register-staged 128 x 128 tile (short row sets)
 void launch_gemm_bf16x3_dma(const GemmX3Args& g, hipStream_t s);            // 256 x 128 tile, async LDS fill (M >= 1024)
 void launch_split3(const float* x, int ldx, long rows, int K, const int* gather, unsigned short* planes,
