@@ -164,6 +164,11 @@ int vx_bench_attn(vx_ctx* ctx, int32_t batch, int32_t len, int32_t causal, int32
 /* counters of the last vx_infer: AR steps run, generated frames, AR / NAR wall milliseconds (stream-synchronised) */
 int vx_last_stats(vx_ctx* ctx, int64_t* ar_steps, int64_t* frames, double* ar_ms, double* nar_ms);
 
+/* number of rows of the last vx_infer whose generation was cut by the ARENA (cfg.max_new frames) before the reference's own stop
+ * rule -- EOS, or more than 16 * text_len frames (models/vallex.py:575-578) -- would have ended it.  0 = every row is what the
+ * reference would have produced; > 0: create the context with a larger max_new. */
+int vx_last_truncated(vx_ctx* ctx, int32_t* rows);
+
 #ifdef __cplusplus
 }
 #endif

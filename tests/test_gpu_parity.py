@@ -185,6 +185,25 @@ def test_generate_audio_api_end_to_end():
     assert wav2.shape[0] == 2 * 10 * 320 and np.isfinite(wav2).all()
 
 
+def test_generate_audio_batch_equals_per_utterance_calls():
+    """the batch form (one inference_batch + one Vocos call; SURVEY section 8 f4 service path) returns, per utterance, exactly
+    what `generate_audio` returns for that utterance alone"""
+    import os
+    from vallex_amd.utils import generation as G
+    sd = synth.vallex_state_dict(2, 11)
+    G.preload_models(state_dict=sd, vocos_state_dict=synth.vocos_state_dict(2), num_layers=2, max_new=320, max_prompt=400,
+                     max_text=256, max_batch=4)
+    pdir = os.path.join(os.path.dirname(__file__), "golden", "presets")
+    texts = [synth.synth_text(12, 31), synth.synth_text(7, 32), synth.synth_text(15, 33)]
+    prompts = [os.path.join(pdir, "paimon.npz"), None, os.path.join(pdir, "cafe.npz")]
+    langs = ["en", "zh", "ja"]
+    us = synth.uniforms(64, 3, 123)
+    batch = G.generate_audio_batch(texts, prompts=prompts, language=langs, uniforms=us, force_eos_at=20)
+    for i in range(3):
+        alone = G.generate_audio(texts[i], prompt=prompts[i], language=langs[i], uniforms=us[:, i], force_eos_at=20)
+        np.testing.assert_array_equal(batch[i], alone)
+
+
 def test_long_text_sliding_window_carries_prompt():
     """generate_audio_from_long_text(mode='sliding-window') with the carry branch always taken (launch-ui.py:493
     behaviour): chunk k+1 is prompted by ALL frames and the text ids of chunk k (utils/generation.py:264-266)."""

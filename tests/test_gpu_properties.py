@@ -70,6 +70,10 @@ def test_stop_rules_lengths():
     row = dict(text=text, prompt=a[0], enroll=3, prompt_language="en", text_language="en")
     assert m.inference_batch([row], top_k=1)[0].shape[0] == 16 * 7
     assert m.inference_batch([row], top_k=1, force_eos_at=17)[0].shape[0] == 17
+    # the arena (max_new) cutting a row before the reference's rule would is reported, not silent
+    small = get_model(2, 1, 1.0, max_new=64, max_prompt=400, max_text=256)
+    with pytest.warns(RuntimeWarning, match="max_new"):
+        assert small.inference_batch([row], top_k=1)[0].shape[0] == 64
 
 
 @pytest.mark.gpu

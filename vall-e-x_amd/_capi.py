@@ -49,7 +49,7 @@ ABI_VERSION = 2       # VX_ABI_VERSION of include/vallex_hip.h this binding was 
 SYMBOLS = ["vx_abi_version", "vx_create", "vx_destroy", "vx_last_error", "vx_synchronize", "vx_load_tensor", "vx_finalize_weights",
            "vx_infer", "vx_vocos_decode", "vx_encodec_decode", "vx_encodec_encode", "vx_ar_prefill", "vx_ar_logits", "vx_ar_step",
            "vx_nar", "vx_read_tap",
-           "vx_prof_enable", "vx_prof_get", "vx_prof_reset", "vx_bench_kernel", "vx_bench_gemm", "vx_bench_attn", "vx_last_stats"]
+           "vx_prof_enable", "vx_prof_get", "vx_prof_reset", "vx_bench_kernel", "vx_bench_gemm", "vx_bench_attn", "vx_last_stats", "vx_last_truncated"]
 
 _lib = None
 
@@ -96,6 +96,7 @@ def load_library() -> C.CDLL:
     lib.vx_bench_gemm.argtypes = [ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P(C.c_double), P(C.c_double)]
     lib.vx_bench_attn.argtypes = [ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P(C.c_double), P(C.c_double)]
     lib.vx_last_stats.argtypes = [ctx, P(C.c_int64), P(C.c_int64), P(C.c_double), P(C.c_double)]
+    lib.vx_last_truncated.argtypes = [ctx, P(C.c_int32)]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("vx_destroy", "vx_last_error", "vx_read_tap", "vx_abi_version"):
@@ -135,7 +136,7 @@ class Engine:
     """Owns one vx_ctx (one GPU).  Not thread-safe; create one per device / process."""
 
     def __init__(self, device_id: int = 0, num_layers: int = 12, max_batch: int = 32, max_text: int = 512,
-                 max_prompt: int = 1024, max_new: int = 2048, use_graph: bool = True, with_vocos: bool = True,
+                 max_prompt: int = 2048, max_new: int = 2048, use_graph: bool = True, with_vocos: bool = True,
                  debug_taps: bool = False, with_encodec: bool = False):
         self.lib = load_library()
         self.cfg = vx_config(C.sizeof(vx_config), num_layers, max_batch, max_text, max_prompt, max_new, int(use_graph), int(with_vocos),
@@ -203,6 +204,13 @@ class Engine:
         lens = np.zeros(batch.n, np.int32)
         self._chk(self.lib.vx_infer(self.ctx, C.byref(batch.c), C.byref(s), _ptr(out, C.c_int64), self.max_new,
                                     _ptr(lens, C.c_int32)))
+        cut = C.c_int32()
+        self._chk(self.lib.vx_last_truncated(self.ctx, C.byref(cut)))
+        if cut.value:
+            import warnings
+            warnings.warn(f"{cut.value} row(s) were cut at the engine's max_new = {self.max_new} frames before the reference's stop "
+                          "rule (EOS or 16 x text length, models/vallex.py:575-578): create the engine with a larger max_new",
+                          RuntimeWarning, stacklevel=2)
         return [out[i, : lens[i]].copy() for i in range(batch.n)]
 
     def vocos_decode(self, codes: Sequence[np.ndarray], bandwidth_id: int = 2):

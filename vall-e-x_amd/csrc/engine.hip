@@ -111,6 +111,7 @@ struct vx_ctx {
   int prof_on = 0;                 // 0 off, 1 every class (AR step runs eagerly), 2 full-sequence classes only
   ProfClass prof[4];
   int64_t st_steps = 0, st_frames = 0;
+  int st_truncated = 0;            // rows of the last vx_infer cut by the arena (max_new) before the reference's stop rule
   double st_ar_ms = 0, st_nar_ms = 0;
 
   // EnCodec decoder (optional)
@@ -1328,7 +1329,11 @@ int vx_infer(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int64_t* out_co
     FAIL(VX_EINVAL, "vx_sampling.struct_size is %u, this library expects %zu (ABI version %d)", s->struct_size, sizeof(vx_sampling), VX_ABI_VERSION);
   if (int e = check_batch(c, b, c->cfg.max_batch)) return e;
   if (!(s->temperature > 0.f)) FAIL(VX_EINVAL, "temperature must be > 0");
-  c->st_steps = 0; c->st_frames = 0; c->st_ar_ms = 0; c->st_nar_ms = 0;
+  c->st_steps = 0; c->st_frames = 0; c->st_ar_ms = 0; c->st_nar_ms = 0; c->st_truncated = 0;
+  // a row that fills the arena although neither EOS, the reference's 16*S cap nor a forced EOS ended it was cut short
+  auto cut_by_arena = [&](int n, int S) {
+    return n >= c->gen_stride && c->gen_stride < 16 * S && !(s->force_eos_at >= 0 && s->force_eos_at <= c->gen_stride);
+  };
   if (s->best_of > 1) {
     // best-of-N beams of ONE utterance (models/vallex.py:491,525-527): the row is replicated N times, every beam
     // samples independently, beams that emit EOS stop; selection on sum(logp) / len^penalty (:583-594), then the NAR
@@ -1356,6 +1361,7 @@ int vx_infer(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int64_t* out_co
     if (int e = nar_generate(c, b, 0, 1, T1, gen.data() + (size_t)pick * c->gen_stride, c->gen_stride, oc, sumT)) return e;
     out_lens[0] = n_gen[pick];
     c->st_frames = n_gen[pick];
+    c->st_truncated = cut_by_arena(n_gen[pick], b->text_lens[0]) ? 1 : 0;
     for (int t = 0; t < n_gen[pick]; ++t) {
       int64_t* o = out_codes + (long)t * N_Q;
       o[0] = gen[(size_t)pick * c->gen_stride + t];
@@ -1383,6 +1389,7 @@ int vx_infer(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int64_t* out_co
     for (int i = 0; i < nb; ++i) {
       out_lens[r0 + i] = n_gen[i];
       c->st_frames += n_gen[i];
+      if (cut_by_arena(n_gen[i], b->text_lens[r0 + i])) ++c->st_truncated;
       for (int t = 0; t < n_gen[i]; ++t) {
         int64_t* o = out_codes + ((long)(r0 + i) * out_stride + t) * N_Q;
         o[0] = gen[(size_t)i * c->gen_stride + t];
@@ -1970,6 +1977,12 @@ int vx_bench_attn(vx_ctx* c, int32_t batch, int32_t len, int32_t causal, int32_t
 #undef TRY
   cleanup();
   HIPCHK(hipGetLastError());
+  return VX_OK;
+}
+
+int vx_last_truncated(vx_ctx* c, int32_t* rows) {
+  if (!c || !rows) return VX_EINVAL;
+  *rows = c->st_truncated;
   return VX_OK;
 }
 

@@ -112,7 +112,7 @@ class VALLE:
         self._device_id = 0
         self.engine_opts = dict(max_batch=int(kwargs.get("engine_max_batch", 32)),
                                 max_text=int(kwargs.get("engine_max_text", 512)),
-                                max_prompt=int(kwargs.get("engine_max_prompt", 1024)),
+                                max_prompt=int(kwargs.get("engine_max_prompt", 2048)),   # >= max_new: sliding-window carry-over
                                 max_new=int(kwargs.get("engine_max_new", 2048)),
                                 use_graph=bool(kwargs.get("engine_use_graph", True)),
                                 debug_taps=bool(kwargs.get("engine_debug_taps", False)))

@@ -171,6 +171,47 @@ def generate_audio(text, prompt=None, language="auto", accent="no-accent", **kw)
     return s.cpu().numpy() if torch is not None and isinstance(s, torch.Tensor) else np.asarray(s)
 
 
+def generate_audio_batch(texts, prompts=None, language="auto", accent="no-accent", text_languages=None, **kw):
+    """Batch form of `generate_audio` (no reference equivalent: the reference synthesises one utterance per call,
+    utils/generation.py:92-152): utterance i of the batch equals `generate_audio(texts[i], prompts[i], language[i], accent)`.
+    `texts`: strings (need the tokenizer hook) or phoneme-id arrays; `prompts`: one preset name / path / None per utterance (or
+    one for all); `language`: one string or one per utterance; `text_languages`: optional per-utterance per-id language lists
+    (what the tokenizer returned, `TextFrontendService`).  All utterances go through ONE `VALLE.inference_batch` call and ONE
+    Vocos call.  Returns a list of float32 waveforms."""
+    if model is None or vocos is None:
+        raise RuntimeError("call preload_models() first")
+    n = len(texts)
+    prompts = list(prompts) if isinstance(prompts, (list, tuple)) else [prompts] * n
+    langs_in = list(language) if isinstance(language, (list, tuple)) else [language] * n
+    text_languages = list(text_languages) if text_languages is not None else [None] * n
+    rows = []
+    for text, prompt, lang_in, tl in zip(texts, prompts, langs_in, text_languages):
+        if isinstance(text, str):
+            text = text.replace("\n", "").strip(" ")
+        lang_in = _detect(text, lang_in)
+        if prompt is not None:
+            audio_prompts, text_prompts, lang_pr = _load_prompt(prompt)
+        else:
+            audio_prompts = np.zeros([1, 0, NUM_QUANTIZERS], np.int32)
+            text_prompts = np.zeros([1, 0], np.int32)
+            lang_pr = None
+        lang_token = lang2token[lang_in]
+        lang = token2lang[lang_token]
+        phone_tokens, langs = _tokenize(text, lang_token)
+        if tl is not None:
+            langs = list(tl)
+        if lang_pr is None:
+            lang_pr = lang if lang != "mix" else "en"
+        lang_eff = lang if accent == "no-accent" else token2lang[langdropdown2token[accent]]
+        text_language = (langs if langs is not None else lang_eff) if accent == "no-accent" else lang_eff
+        if text_language == "mix":
+            raise KeyError("mix")
+        rows.append(dict(text=np.concatenate([text_prompts.reshape(-1), phone_tokens]), prompt=audio_prompts[0],
+                         enroll=text_prompts.shape[-1], prompt_language=lang_pr, text_language=text_language))
+    codes = model.inference_batch(rows, top_k=-100, temperature=1, **kw)
+    return model.engine.vocos_decode(codes, 2)
+
+
 def generate_audio_from_long_text(text, prompt=None, language="auto", accent="no-accent", mode="sliding-window", **kw):
     """utils/generation.py:155-276.  `text` may also be a list of sentences / id arrays (pre-split)."""
     if model is None or vocos is None:
