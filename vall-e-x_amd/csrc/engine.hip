@@ -1781,8 +1781,19 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
     HIPCHK(hipEventRecord(e1, c->stream));
     launches = reps * 4;
     bytes = 12.0 * D_MODEL * D_MODEL * 4.0 / 4.0;     // per launch: a layer's 12 d^2 weights over its 4 GEMMs
+  } else if (which == 2) {
+    // cache-retention probe: the SAME weight-streaming GEMM (layer 0 QKV, 12.6 MB) back to back -- what a launch costs when
+    // its weights were read a moment ago (memory-side cache hits) instead of coming cold from HBM (which 1)
+    const LayerW& L = c->ar[0];
+    auto one = [&]() { launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, nullptr, c->stream); };
+    one();
+    HIPCHK(hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; ++r) one();
+    HIPCHK(hipEventRecord(e1, c->stream));
+    launches = reps;
+    bytes = 3.0 * D_MODEL * D_MODEL * 4.0;
   } else {
-    FAIL(VX_EINVAL, "which must be 0 or 1");
+    FAIL(VX_EINVAL, "which must be 0, 1 or 2");
   }
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0;
