@@ -260,68 +260,59 @@ __device__ __forceinline__ void ln_pack_row(const f32x4 (&v)[4], int b, const f3
 
 // h[b] = resid[b] + (sum_ks partial[ks][b] + bias);  xp = pack(LN(h)).  partial may be null (splitk = 0).
 // modules/transformer.py:345-346 (x = x + attn_out ; x = x + ff(norm2(x))) fused with the next norm.
-// Slabs are summed in ascending ks order, 8 at a time (all 8 x 4 loads of a chunk in flight together).
+// One 256-thread block per batch row, thread t owns float4 column t of the 1024: SK + 4 independent 16-byte loads per thread
+// (a single wave per row had to pull 36-68 KB by itself: 64 loads per lane), slabs summed in ascending ks order, LayerNorm
+// statistics (two-pass) through two 4-wave LDS exchanges.
 template <int SK>
-__global__ __launch_bounds__(64) void dec_reduce_ln_pack_kernel(const float* __restrict__ partial, int npad,
-                                                                const float* __restrict__ bias,
-                                                                const float* __restrict__ resid,
-                                                                float* __restrict__ h, const float* __restrict__ g,
-                                                                const float* __restrict__ bb,
-                                                                float* __restrict__ xp) {
-  const int b = blockIdx.x, lane = threadIdx.x;
-  constexpr int CH = SK > 8 ? 8 : (SK > 0 ? SK : 1);
-  f32x4 v[4], gg[4], be[4], r[4], bi[4], p[CH][4];
+__global__ __launch_bounds__(256) void dec_reduce_ln_pack_kernel(const float* __restrict__ partial, int npad,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ resid,
+                                                                 float* __restrict__ h, const float* __restrict__ g,
+                                                                 const float* __restrict__ bb,
+                                                                 float* __restrict__ xp) {
+  __shared__ float red[2][4];
+  const int b = blockIdx.x, t = threadIdx.x, wid = t >> 6, c = t * 4;
+  f32x4 p[SK > 0 ? SK : 1];
 #pragma unroll
-  for (int ks = 0; ks < (SK < CH ? SK : CH); ++ks)
+  for (int ks = 0; ks < SK; ++ks) p[ks] = *reinterpret_cast<const f32x4*>(partial + ((long)ks * MB + b) * npad + c);
+  const f32x4 gg = *reinterpret_cast<const f32x4*>(g + c), be = *reinterpret_cast<const f32x4*>(bb + c);
+  f32x4 r = {0.f, 0.f, 0.f, 0.f}, bi = {0.f, 0.f, 0.f, 0.f};
+  if (resid) r = *reinterpret_cast<const f32x4*>(resid + (long)b * D_MODEL + c);
+  if (SK > 0 && bias) bi = *reinterpret_cast<const f32x4*>(bias + c);
+  f32x4 v = SK > 0 ? p[0] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      p[ks][i] = *reinterpret_cast<const f32x4*>(partial + ((long)ks * MB + b) * npad + (lane + 64 * i) * 4);
+  for (int ks = 1; ks < SK; ++ks)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = (lane + 64 * i) * 4;
-    gg[i] = *reinterpret_cast<const f32x4*>(g + c);
-    be[i] = *reinterpret_cast<const f32x4*>(bb + c);
-    if (resid) r[i] = *reinterpret_cast<const f32x4*>(resid + (long)b * D_MODEL + c);
-    if (SK > 0 && bias) bi[i] = *reinterpret_cast<const f32x4*>(bias + c);
-  }
+    for (int e = 0; e < 4; ++e) v[e] += p[ks][e];
+  if (SK > 0 && bias)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = SK > 0 ? p[0][i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int e = 0; e < 4; ++e) v[e] += bi[e];
+  if (resid)
 #pragma unroll
-  for (int ks = 1; ks < (SK < CH ? SK : CH); ++ks)
+    for (int e = 0; e < 4; ++e) v[e] = r[e] + v[e];
+  if (h) *reinterpret_cast<f32x4*>(h + (long)b * D_MODEL + c) = v;
+  // LayerNorm (F.layer_norm, eps 1e-5): mean, then the centred second moment
+  float s1 = wave_sum64((v[0] + v[1]) + (v[2] + v[3]));
+  if ((t & 63) == 0) red[0][wid] = s1;
+  __syncthreads();
+  const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * (1.0f / D_MODEL);
+  float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+  for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q += d * d; }
+  q = wave_sum64(q);
+  if ((t & 63) == 0) red[1][wid] = q;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * (1.0f / D_MODEL) + LN_EPS);
+  f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[i][e] += p[ks][i][e];
-#pragma unroll
-  for (int k0 = CH; k0 < SK; k0 += CH) {
-#pragma unroll
-    for (int ks = 0; ks < CH; ++ks)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        p[ks][i] = *reinterpret_cast<const f32x4*>(partial + ((long)(k0 + ks) * MB + b) * npad + (lane + 64 * i) * 4);
-#pragma unroll
-    for (int ks = 0; ks < CH; ++ks)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[i][e] += p[ks][i][e];
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (SK > 0 && bias)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[i][e] += bi[i][e];
-    if (resid)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[i][e] = r[i][e] + v[i][e];
-    if (h) *reinterpret_cast<f32x4*>(h + (long)b * D_MODEL + (lane + 64 * i) * 4) = v[i];
-  }
-  ln_pack_row(v, b, gg, be, xp);
+  for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * gg[e] + be[e];
+  // packed-x image: float4 column c4 = t -> kb = c4 >> 1, hi = c4 & 1
+  *reinterpret_cast<f32x4*>(xp + (((long)(t >> 1) * 64) + b + 32 * (t & 1)) * 4) = o;
 }
 
 void launch_dec_reduce_ln_pack(const float* partial, int splitk, int npad, const float* bias, const float* resid,
                                float* h, const float* g, const float* b, float* xp, int batch, hipStream_t s) {
-#define VX_RLP(SKV) hipLaunchKernelGGL((dec_reduce_ln_pack_kernel<SKV>), dim3(batch), dim3(64), 0, s, partial, npad, bias, resid, h, g, b, xp)
+#define VX_RLP(SKV) hipLaunchKernelGGL((dec_reduce_ln_pack_kernel<SKV>), dim3(batch), dim3(256), 0, s, partial, npad, bias, resid, h, g, b, xp)
   if (splitk == 0) VX_RLP(0);
   else if (splitk == 4) VX_RLP(4);
   else if (splitk == 8) VX_RLP(8);
