@@ -129,7 +129,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
   }
   auto dma = [&](unsigned char* stage, int kt) {
 #pragma unroll
-    for (int j = 0; j < HNDMA; ++j)
+    for (int j = 0; j < (V == 10 ? 4 : HNDMA); ++j)            // probe 10: two thirds of the operand bytes (results meaningless)
       __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + kt * kstep[j]), (lptr_t)(stage + lds_off[j]), 16, 0, 0);
   };
 
@@ -256,6 +256,7 @@ void launch_gemm_f16x2_probe(const GemmX3Args& g, int variant, hipStream_t s) {
   else if (variant == 7) hipLaunchKernelGGL(gemm_f16x2_kernel<7>, grid, block, 0, s, g);
   else if (variant == 8) hipLaunchKernelGGL(gemm_f16x2_kernel<8>, grid, block, 0, s, g);
   else if (variant == 9) hipLaunchKernelGGL(gemm_f16x2_kernel<9>, grid, block, 0, s, g);
+  else if (variant == 10) hipLaunchKernelGGL(gemm_f16x2_kernel<10>, grid, block, 0, s, g);
   else hipLaunchKernelGGL(gemm_f16x2_kernel<4>, grid, block, 0, s, g);
 }
 #endif
