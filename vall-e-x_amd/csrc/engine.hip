@@ -76,6 +76,7 @@ struct vx_ctx {
   int gemm_mode = 0;
   bool attn_x3 = true;                        // bf16x3 attention (attn_full_x3.hip); VX_ATTN_F32=1 keeps the fp32 MFMA kernel
   int* range_flag = nullptr;       // device flag: an operand of an f16x2 GEMM did not fit fp16 (checked after every phase)
+  unsigned short* fa3b = nullptr;  // second plane buffer: linear1 writes linear2's A planes straight from its epilogue (f16x2 mode)
   unsigned short* fa3 = nullptr;   // activation planes [2 or 3][M][K<=4096]
   unsigned short* pred_w3[N_Q - 1] = {};
   // full-sequence arena
@@ -243,18 +244,25 @@ void gemm(vx_ctx* c, const float* A, int lda, const float* Wt, int ldw, const fl
 }
 
 // transformer projection (F.linear of modules/activation.py:144,166, modules/transformer.py:371-373, models/vallex.py:677)
+// f16x2 mode extras: `a_pre` = A operand already in plane form (skip the split pass); `out_pl` = write the result as the next
+// GEMM's A planes (K = N) instead of fp32 rows (C may then be null).
 void proj(vx_ctx* c, const float* A, int lda, const float* Wf, const unsigned short* W3, const float* bias,
-          const float* resid, int ldr, float* C, int ldc, long M, int N, int K, int act, const int* gather = nullptr) {
+          const float* resid, int ldr, float* C, int ldc, long M, int N, int K, int act, const int* gather = nullptr,
+          const unsigned short* a_pre = nullptr, unsigned short* out_pl = nullptr) {
   if (c->gemm_mode == 2 || !W3) {
     gemm(c, A, lda, Wf, K, bias, resid, ldr, nullptr, C, ldc, M, N, K, act, gather);
     return;
   }
   const long a_plane = c->gemm_mode == 0 ? h2_plane(M, K, H2_TILE_A) : (long)M * K;
-  if (c->gemm_mode == 0) launch_split2h(A, lda, M, K, gather, c->fa3, a_plane, H2_TILE_A, c->range_flag, c->stream);
-  else launch_split3(A, lda, M, K, gather, c->fa3, a_plane, c->stream);
+  if (!a_pre) {
+    if (c->gemm_mode == 0) launch_split2h(A, lda, M, K, gather, c->fa3, a_plane, H2_TILE_A, c->range_flag, c->stream);
+    else launch_split3(A, lda, M, K, gather, c->fa3, a_plane, c->stream);
+  }
   GemmX3Args g{};
-  g.A = c->fa3; g.a_plane = a_plane; g.W = W3; g.w_plane = c->gemm_mode == 0 ? h2_plane(N, K, H2_TILE_W) : (long)N * K; g.bias = bias; g.resid = resid; g.ldr = ldr;
+  g.A = a_pre ? a_pre : c->fa3; g.a_plane = a_plane; g.W = W3; g.w_plane = c->gemm_mode == 0 ? h2_plane(N, K, H2_TILE_W) : (long)N * K;
+  g.bias = bias; g.resid = resid; g.ldr = ldr;
   g.colscale = nullptr; g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.act = act;
+  g.out_planes = out_pl; g.out_plane = out_pl ? h2_plane(M, N, H2_TILE_A) : 0; g.range_flag = c->range_flag;
   ProfScope ps(c, 2);
   if (c->prof_on) c->prof[2].bytes += 2.0 * (double)M * N * K;
   if (c->gemm_mode == 0) launch_gemm_f16x2(g, c->stream);
@@ -279,8 +287,14 @@ int full_layer(vx_ctx* c, const LayerW& L, long M, const int* seq_off, const int
   proj(c, c->fatt, D_MODEL, L.out_w, L.out_w3, L.out_b, c->fx, D_MODEL, c->fx, D_MODEL, M, D_MODEL, D_MODEL, ACT_NONE);
   launch_layernorm(c->fx, D_MODEL, c->fxn, D_MODEL, (int)M, D_MODEL, LN_EPS, L.n2_w, L.n2_b, ada2,
                    ada2 ? ada2 + D_MODEL : nullptr, c->stream);
-  proj(c, c->fxn, D_MODEL, L.l1_w, L.l1_w3, L.l1_b, nullptr, 0, c->fffn, D_FF, M, D_FF, D_MODEL, ACT_RELU);
-  proj(c, c->fffn, D_FF, L.l2_w, L.l2_w3, L.l2_b, c->fx, D_MODEL, c->fx, D_MODEL, M, D_MODEL, D_FF, ACT_NONE);
+  if (c->gemm_mode == 0) {
+    // linear1's epilogue writes relu(x W1^T + b1) directly as linear2's f16x2 A planes: no fp32 [M][4096] round trip, no split pass
+    proj(c, c->fxn, D_MODEL, L.l1_w, L.l1_w3, L.l1_b, nullptr, 0, nullptr, D_FF, M, D_FF, D_MODEL, ACT_RELU, nullptr, nullptr, c->fa3b);
+    proj(c, nullptr, D_FF, L.l2_w, L.l2_w3, L.l2_b, c->fx, D_MODEL, c->fx, D_MODEL, M, D_MODEL, D_FF, ACT_NONE, nullptr, c->fa3b);
+  } else {
+    proj(c, c->fxn, D_MODEL, L.l1_w, L.l1_w3, L.l1_b, nullptr, 0, c->fffn, D_FF, M, D_FF, D_MODEL, ACT_RELU);
+    proj(c, c->fffn, D_FF, L.l2_w, L.l2_w3, L.l2_b, c->fx, D_MODEL, c->fx, D_MODEL, M, D_MODEL, D_FF, ACT_NONE);
+  }
   return VX_OK;
 }
 
@@ -920,6 +934,7 @@ int vx_finalize_weights(vx_ctx* c) {
     for (int j = 0; j < N_Q - 1; ++j)
       if ((e = split_w(W(c, "nar_predict_layers." + std::to_string(j) + ".weight"), AUDIO_VOCAB, d, &c->pred_w3[j]))) return e;
     if ((e = dev_alloc(c, &c->fa3, (size_t)P * (c->Mmax + 256) * f))) return e;       // zeroed: the pad rows of a last tile are read
+    if (c->gemm_mode == 0 && (e = dev_alloc(c, &c->fa3b, (size_t)2 * (c->Mmax + 256) * f))) return e;
   }
 
   // ---- packed decode images of the AR stack ----

@@ -203,13 +203,20 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
   }
   if (V == 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
 
-  // epilogue: C = heads + cross / 2048 (+ bias, activation, residual as in the bf16x3 kernels)
+  // epilogue: C = heads + cross / 2048 (+ bias, activation, residual as in the bf16x3 kernels).
+  // With g.out_planes set, the result is NOT written as fp32 rows: it is split on the spot into the f16x2 planes of the NEXT
+  // GEMM's A operand (tile-major, K = this N), so linear1 -> linear2 needs neither an fp32 round trip of the [M][4096] hidden
+  // activations nor a split pass.  The 32 columns of a (jn) block are exactly one K tile of the consumer; lanes l and l ^ 32 hold
+  // complementary 4-column halves of each 8-column group, so they trade halves (one ds_bpermute per word) and every lane stores
+  // 16 contiguous bytes per plane.  Same conversions as split2h_kernel => bit-identical planes.
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + wm * 64 + i * 32 + l31;
     if (m >= g.M) continue;
 #pragma unroll
     for (int jn = 0; jn < 2; ++jn) {
+      unsigned hw[4][2], tw[4][2];                               // [g4][pair]: packed fp16 heads / scaled tails (planes mode)
+      bool bad = false;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int n = n0 + wn * 64 + jn * 32 + 8 * g4 + 4 * hi;
@@ -231,7 +238,46 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = rr[e] + v[e];
         }
-        *reinterpret_cast<f32x4*>(g.C + (long)m * g.ldc + n) = v;
+        if (!g.out_planes) {
+          *reinterpret_cast<f32x4*>(g.C + (long)m * g.ldc + n) = v;
+        } else {
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+            f16x2v h2, t2;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const float x = v[2 * pr + q];
+              bad |= !(fabsf(x) < 65504.0f);
+              h2[q] = (_Float16)x;                               // RNE, as split2h_kernel
+              t2[q] = (_Float16)((x - (float)h2[q]) * TAIL_SCALE);
+            }
+            hw[g4][pr] = __builtin_bit_cast(unsigned, h2);
+            tw[g4][pr] = __builtin_bit_cast(unsigned, t2);
+          }
+        }
+      }
+      if (g.out_planes) {
+        // consumer plane element (m, k = n): ((m / 256) * (N / 32) + n / 32) * 256 * 32 + (m % 256) * 32 + n % 32
+        const long blk = ((long)tm * (g.N / HK) + (n0 + wn * 64 + jn * 32) / HK) * (HM * HK) + (long)(wm * 64 + i * 32 + l31) * HK;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                            // columns 16 j .. 16 j + 15 of the K tile
+          // lane hi = 0 keeps its g4 = 2j words and wants the partner's g4 = 2j words; lane hi = 1 keeps g4 = 2j + 1
+          const int keep = 2 * j + hi, give = 2 * j + 1 - hi;
+          unsigned rh[2], rt[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            rh[q] = (unsigned)__shfl_xor((int)hw[give][q], 32, 64);
+            rt[q] = (unsigned)__shfl_xor((int)tw[give][q], 32, 64);
+          }
+          typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+          const u32x4v oh = hi ? u32x4v{rh[0], rh[1], hw[keep][0], hw[keep][1]} : u32x4v{hw[keep][0], hw[keep][1], rh[0], rh[1]};
+          const u32x4v ot = hi ? u32x4v{rt[0], rt[1], tw[keep][0], tw[keep][1]} : u32x4v{tw[keep][0], tw[keep][1], rt[0], rt[1]};
+          unsigned short* o = g.out_planes + blk + 16 * j + 8 * hi;
+          *reinterpret_cast<u32x4v*>(o) = oh;
+          *reinterpret_cast<u32x4v*>(o + g.out_plane) = ot;
+        }
+        if (bad && g.range_flag) *g.range_flag = 1;
       }
     }
   }

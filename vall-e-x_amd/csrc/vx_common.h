@@ -50,6 +50,9 @@ struct GemmX3Args {
   float* C; int ldc;
   int M, N, K;
   int act;
+  // f16x2 only, optional: write the result as the f16x2 A planes of the NEXT GEMM (tile-major, K = this N) instead of fp32 rows
+  unsigned short* out_planes; long out_plane;   // plane stride in elements: h2_plane(M, N, H2_TILE_A)
+  int* range_flag;
 };
 void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s);                 // 256 x 128 x 32 tile, async LDS fill, any M
 // f16x2 planes are TILE-major: [rows / tile_rows][K/32][tile_rows][32], tile_rows = 256 (A operand) or 128 (W operand);
