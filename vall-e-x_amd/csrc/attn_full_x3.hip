@@ -134,7 +134,8 @@ template <int V>
 __global__ __launch_bounds__(256, 2) void attn_full_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                              const int* __restrict__ seq_off,
                                                              const int* __restrict__ seq_len,
-                                                             const int* __restrict__ prefix_len, int nqb) {
+                                                             const int* __restrict__ prefix_len, int nqb,
+                                                             unsigned short* __restrict__ planes, long plane_stride) {
   __shared__ __attribute__((aligned(16))) unsigned char Kp[3][3][KP_SZ];   // [buffer][plane]
   __shared__ __attribute__((aligned(16))) unsigned char Vt[3][3][VT_SZ];
 
@@ -408,33 +409,74 @@ __global__ __launch_bounds__(256, 2) void attn_full_x3_kernel(const float* __res
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (qi < len) {
     const float inv = 1.0f / l_tot;
-    float* op = out + (row0 + qi) * (long)D_MODEL + h * D_HEAD + 4 * hi;
+    if (!planes) {
+      float* op = out + (row0 + qi) * (long)D_MODEL + h * D_HEAD + 4 * hi;
 #pragma unroll
-    for (int half = 0; half < 2; ++half)
+      for (int half = 0; half < 2; ++half)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        f32x4 t;
+        for (int g4 = 0; g4 < 4; ++g4) {
+          f32x4 t;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = o[half][g4 * 4 + e] * inv;
-        *reinterpret_cast<f32x4*>(op + half * 32 + g4 * 8) = t;   // d = 32*half + 8*g4 + 4*hi + e
+          for (int e = 0; e < 4; ++e) t[e] = o[half][g4 * 4 + e] * inv;
+          *reinterpret_cast<f32x4*>(op + half * 32 + g4 * 8) = t;   // d = 32*half + 8*g4 + 4*hi + e
+        }
+    } else {
+      // the attention output only feeds out_proj: write it as that GEMM's f16x2 A planes (tile-major, K = 1024; the 32 dims of
+      // `half` are one K tile, index 2 h + half).  Lanes l and l ^ 32 hold complementary 4-dim halves of every 8-dim group and
+      // trade them, so each lane stores 16 contiguous bytes per plane (same scheme as the GEMM's plane epilogue).
+      typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+      const long row = row0 + qi;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        unsigned hw[4][2], tw[4][2];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            h2_t h2, t2;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const float xv = o[half][g4 * 4 + 2 * pr + k] * inv;
+              h2[k] = (_Float16)xv;
+              t2[k] = (_Float16)((xv - (float)h2[k]) * 2048.0f);
+            }
+            hw[g4][pr] = __builtin_bit_cast(unsigned, h2);
+            tw[g4][pr] = __builtin_bit_cast(unsigned, t2);
+          }
+        unsigned short* blk = planes + (((row >> 8) * (D_MODEL / 32) + (2 * h + half)) * 256 + (row & 255)) * 32;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int keep = 2 * j + hi, give = 2 * j + 1 - hi;
+          unsigned rh[2], rt[2];
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            rh[k] = (unsigned)__shfl_xor((int)hw[give][k], 32, 64);
+            rt[k] = (unsigned)__shfl_xor((int)tw[give][k], 32, 64);
+          }
+          const u32x4 oh = hi ? u32x4{rh[0], rh[1], hw[keep][0], hw[keep][1]} : u32x4{hw[keep][0], hw[keep][1], rh[0], rh[1]};
+          const u32x4 ot = hi ? u32x4{rt[0], rt[1], tw[keep][0], tw[keep][1]} : u32x4{tw[keep][0], tw[keep][1], rt[0], rt[1]};
+          *reinterpret_cast<u32x4*>(blk + 16 * j + 8 * hi) = oh;
+          *reinterpret_cast<u32x4*>(blk + 16 * j + 8 * hi + plane_stride) = ot;
+        }
       }
+    }
   }
 }
 
 void launch_attn_full_x3(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
-                         int batch, int max_len, int variant, hipStream_t s) {
+                         int batch, int max_len, int variant, hipStream_t s, unsigned short* planes, long plane_stride) {
   if (batch <= 0 || max_len <= 0) return;
   const int nqb = (max_len + QB - 1) / QB;                   // batch * N_HEAD is a multiple of 8 (16 heads)
   const dim3 grid(nqb * N_HEAD * batch), block(256);
 #ifdef VX_DEV_PROBES
-  if (variant == 1) hipLaunchKernelGGL(attn_full_x3_kernel<1>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
-  else if (variant == 2) hipLaunchKernelGGL(attn_full_x3_kernel<2>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
-  else if (variant == 3) hipLaunchKernelGGL(attn_full_x3_kernel<3>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
-  else if (variant == 4) hipLaunchKernelGGL(attn_full_x3_kernel<4>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
-  else if (variant == 5) hipLaunchKernelGGL(attn_full_x3_kernel<5>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
+  if (variant == 1) hipLaunchKernelGGL(attn_full_x3_kernel<1>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, planes, plane_stride);
+  else if (variant == 2) hipLaunchKernelGGL(attn_full_x3_kernel<2>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, planes, plane_stride);
+  else if (variant == 3) hipLaunchKernelGGL(attn_full_x3_kernel<3>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, planes, plane_stride);
+  else if (variant == 4) hipLaunchKernelGGL(attn_full_x3_kernel<4>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, planes, plane_stride);
+  else if (variant == 5) hipLaunchKernelGGL(attn_full_x3_kernel<5>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, planes, plane_stride);
   else
 #endif
-  hipLaunchKernelGGL(attn_full_x3_kernel<0>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
+  hipLaunchKernelGGL(attn_full_x3_kernel<0>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, planes, plane_stride);
 }
 
 }  // namespace vx

@@ -274,22 +274,31 @@ void proj(vx_ctx* c, const float* A, int lda, const float* Wf, const unsigned sh
 int full_layer(vx_ctx* c, const LayerW& L, long M, const int* seq_off, const int* seq_len, const int* prefix_len,
                int batch, int max_len, const float* ada1, const float* ada2, float* kcl, float* vcl,
                const int* row_b, const int* row_t, double attn_flops) {
-  launch_layernorm(c->fx, D_MODEL, c->fxn, D_MODEL, (int)M, D_MODEL, LN_EPS, L.n1_w, L.n1_b, ada1,
-                   ada1 ? ada1 + D_MODEL : nullptr, c->stream);
-  proj(c, c->fxn, D_MODEL, L.in_w, L.in_w3, L.in_b, nullptr, 0, c->fqkv, 3 * D_MODEL, M, 3 * D_MODEL, D_MODEL, ACT_NONE);
+  // f16x2 mode: every producer of a GEMM operand (the two LayerNorms, the attention, linear1's epilogue) writes the operand
+  // planes itself -- no fp32 round trip of the normalised / attended / hidden activations and no split pass on any edge.
+  const bool pl = c->gemm_mode == 0;
+  const long pl1024 = h2_plane(M, D_MODEL, H2_TILE_A);
+  launch_layernorm(c->fx, D_MODEL, pl ? nullptr : c->fxn, D_MODEL, (int)M, D_MODEL, LN_EPS, L.n1_w, L.n1_b, ada1,
+                   ada1 ? ada1 + D_MODEL : nullptr, c->stream, pl ? c->fa3 : nullptr, pl1024, c->range_flag);
+  proj(c, c->fxn, D_MODEL, L.in_w, L.in_w3, L.in_b, nullptr, 0, c->fqkv, 3 * D_MODEL, M, 3 * D_MODEL, D_MODEL, ACT_NONE, nullptr,
+       pl ? c->fa3 : nullptr);
   if (kcl) launch_kv_scatter(c->fqkv, row_b, row_t, (int)M, kcl, vcl, c->Tmax, c->stream);
+  const bool att_pl = pl && c->attn_x3;
   {
     ProfScope ps(c, 3);
     if (c->prof_on) c->prof[3].bytes += attn_flops;
-    if (c->attn_x3) launch_attn_full_x3(c->fqkv, c->fatt, seq_off, seq_len, prefix_len, batch, max_len, 0, c->stream);
+    if (c->attn_x3)
+      launch_attn_full_x3(c->fqkv, att_pl ? nullptr : c->fatt, seq_off, seq_len, prefix_len, batch, max_len, 0, c->stream,
+                          att_pl ? c->fa3 : nullptr, pl1024);
     else launch_attn_full(c->fqkv, c->fatt, seq_off, seq_len, prefix_len, batch, max_len, c->stream);
   }
-  proj(c, c->fatt, D_MODEL, L.out_w, L.out_w3, L.out_b, c->fx, D_MODEL, c->fx, D_MODEL, M, D_MODEL, D_MODEL, ACT_NONE);
-  launch_layernorm(c->fx, D_MODEL, c->fxn, D_MODEL, (int)M, D_MODEL, LN_EPS, L.n2_w, L.n2_b, ada2,
-                   ada2 ? ada2 + D_MODEL : nullptr, c->stream);
-  if (c->gemm_mode == 0) {
-    // linear1's epilogue writes relu(x W1^T + b1) directly as linear2's f16x2 A planes: no fp32 [M][4096] round trip, no split pass
-    proj(c, c->fxn, D_MODEL, L.l1_w, L.l1_w3, L.l1_b, nullptr, 0, nullptr, D_FF, M, D_FF, D_MODEL, ACT_RELU, nullptr, nullptr, c->fa3b);
+  proj(c, c->fatt, D_MODEL, L.out_w, L.out_w3, L.out_b, c->fx, D_MODEL, c->fx, D_MODEL, M, D_MODEL, D_MODEL, ACT_NONE, nullptr,
+       att_pl ? c->fa3 : nullptr);
+  launch_layernorm(c->fx, D_MODEL, pl ? nullptr : c->fxn, D_MODEL, (int)M, D_MODEL, LN_EPS, L.n2_w, L.n2_b, ada2,
+                   ada2 ? ada2 + D_MODEL : nullptr, c->stream, pl ? c->fa3 : nullptr, pl1024, c->range_flag);
+  if (pl) {
+    // linear1's epilogue writes relu(x W1^T + b1) directly as linear2's A planes
+    proj(c, nullptr, D_MODEL, L.l1_w, L.l1_w3, L.l1_b, nullptr, 0, nullptr, D_FF, M, D_FF, D_MODEL, ACT_RELU, nullptr, c->fa3, c->fa3b);
     proj(c, nullptr, D_FF, L.l2_w, L.l2_w3, L.l2_b, c->fx, D_MODEL, c->fx, D_MODEL, M, D_MODEL, D_FF, ACT_NONE, nullptr, c->fa3b);
   } else {
     proj(c, c->fxn, D_MODEL, L.l1_w, L.l1_w3, L.l1_b, nullptr, 0, c->fffn, D_FF, M, D_FF, D_MODEL, ACT_RELU);

@@ -16,11 +16,17 @@ __device__ __forceinline__ float wave_sum(float v) {
 // stage embedding is input independent and precomputed at load).  Vocos AdaLayerNorm is the g=b=null case.
 // Two-pass statistics from registers (mean, then centred sum of squares) in fp32.
 // ---------------------------------------------------------------------------------------------
+// planes != null (C = 1024 only): the result is ALSO / INSTEAD (y may be null) written as the f16x2 operand planes of the GEMM that
+// consumes it (tile-major [rows/256][C/32][256][32], head and scaled tail; same conversions as split2h_kernel => bit-identical
+// planes): the LayerNorm -> QKV / linear1 edges need no fp32 round trip and no split pass.  Adjacent lanes hold adjacent 4-column
+// groups; they trade words through one DPP swap so the even lane stores 16 B of the head plane and the odd lane 16 B of the
+// tail plane.
 template <int C, int VEC>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int ldx, float* y,
                                                         int ldy, int rows, float eps, const float* __restrict__ g,
                                                         const float* __restrict__ b, const float* __restrict__ aw,
-                                                        const float* __restrict__ ab) {
+                                                        const float* __restrict__ ab, unsigned short* __restrict__ planes,
+                                                        long plane_stride, int* __restrict__ range_flag) {
   constexpr int PER = C / (64 * VEC);
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -40,7 +46,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int ldx,
 #pragma unroll
   for (int i = 0; i < PER * VEC; ++i) { const float d = v[i] - mean; q += d * d; }
   const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / C) + eps);
-  float* yr = y + (long)row * ldy;
+  float* yr = y ? y + (long)row * ldy : nullptr;
+  bool bad = false;
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int c = (i * 64 + lane) * VEC;
@@ -60,18 +67,51 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int ldx,
 #pragma unroll
       for (int e = 0; e < VEC; ++e) o[e] = t0[e] * o[e] + t1[e];
     }
-    *reinterpret_cast<vec_t*>(yr + c) = o;
+    if (yr) *reinterpret_cast<vec_t*>(yr + c) = o;
+    if constexpr (VEC == 4 && C == 1024) {
+      if (planes) {
+        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+        typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+        unsigned hw[2], tw[2];
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          h2_t h2, t2;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const float xv = o[2 * pr + k];
+            bad |= !(fabsf(xv) < 65504.0f);
+            h2[k] = (_Float16)xv;                                      // RNE, as split2h_kernel
+            t2[k] = (_Float16)((xv - (float)h2[k]) * 2048.0f);
+          }
+          hw[pr] = __builtin_bit_cast(unsigned, h2);
+          tw[pr] = __builtin_bit_cast(unsigned, t2);
+        }
+        const bool odd = lane & 1;
+        unsigned r0 = odd ? hw[0] : tw[0], r1 = odd ? hw[1] : tw[1];   // what the neighbour lane needs
+        r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)r0, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: swap with lane ^ 1
+        r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)r1, 0xB1, 0xF, 0xF, true);
+        // columns 8 (c / 8) .. + 7 of the row: the even lane owns the first four, the odd lane the last four
+        const int c8 = c & ~7;
+        unsigned short* dst = planes + (((long)(row >> 8) * (C / 32) + (c8 >> 5)) * 256 + (row & 255)) * 32 + (c8 & 31);
+        if (!odd) *reinterpret_cast<u4_t*>(dst) = u4_t{hw[0], hw[1], r0, r1};                       // head plane
+        else *reinterpret_cast<u4_t*>(dst + plane_stride) = u4_t{r0, r1, tw[0], tw[1]};             // tail plane
+      }
+    }
   }
+  if (bad && range_flag) *range_flag = 1;
 }
 
 void launch_layernorm(const float* x, int ldx, float* y, int ldy, int rows, int C, float eps, const float* g,
-                      const float* b, const float* aw, const float* ab, hipStream_t s) {
+                      const float* b, const float* aw, const float* ab, hipStream_t s, unsigned short* planes,
+                      long plane_stride, int* range_flag) {
   if (rows <= 0) return;
   dim3 grid((rows + 3) / 4), block(256);
   if (C == 1024)
-    hipLaunchKernelGGL((layernorm_kernel<1024, 4>), grid, block, 0, s, x, ldx, y, ldy, rows, eps, g, b, aw, ab);
+    hipLaunchKernelGGL((layernorm_kernel<1024, 4>), grid, block, 0, s, x, ldx, y, ldy, rows, eps, g, b, aw, ab, planes,
+                       plane_stride, range_flag);
   else
-    hipLaunchKernelGGL((layernorm_kernel<384, 2>), grid, block, 0, s, x, ldx, y, ldy, rows, eps, g, b, aw, ab);
+    hipLaunchKernelGGL((layernorm_kernel<384, 2>), grid, block, 0, s, x, ldx, y, ldy, rows, eps, g, b, aw, ab, nullptr, 0L,
+                       nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -73,8 +73,10 @@ void launch_gemm_f16x2_probe(const GemmX3Args& g, int variant, hipStream_t s);
 
 // ---- row-wise ops (rows.hip) --------------------------------------------------------------------
 // y = (LN(x) * g + b) [* ada_w + ada_b]; any of g/b/ada_* may be null.  C in {1024, 384}.
+// planes (C = 1024 only, optional; y may then be null): also write the f16x2 A planes of the consuming GEMM (tile-major, K = C)
 void launch_layernorm(const float* x, int ldx, float* y, int ldy, int rows, int C, float eps, const float* g,
-                      const float* b, const float* ada_w, const float* ada_b, hipStream_t s);
+                      const float* b, const float* ada_w, const float* ada_b, hipStream_t s,
+                      unsigned short* planes = nullptr, long plane_stride = 0, int* range_flag = nullptr);
 // out[dst? dst[r] : r] = tabA[idA[r]] (+ tabB[idB[r]] if idB && idB[r] >= 0) + alpha * pe[pos[r]]   (rows of 1024)
 void launch_embed_rows(float* out, const int* dst, const float* tabA, const int* idA, const float* tabB,
                        const int* idB, const float* alpha, const float* pe, const int* pos, int rows, hipStream_t s);
@@ -103,8 +105,10 @@ void launch_attn_full(const float* qkv, float* out, const int* seq_off, const in
                       int batch, int max_len, hipStream_t s);
 
 // bf16x3 version (attn_full_x3.hip), the product path; variant 0 = product (1-5 = timing probes, VX_DEV_PROBES builds only)
+// planes (optional; out may then be null): write the result as the f16x2 A planes of out_proj (tile-major, K = 1024)
 void launch_attn_full_x3(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
-                         int batch, int max_len, int variant, hipStream_t s);
+                         int batch, int max_len, int variant, hipStream_t s, unsigned short* planes = nullptr,
+                         long plane_stride = 0);
 #ifdef VX_DEV_PROBES
 void launch_attn_full_probe(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
                             int batch, int max_len, int variant, hipStream_t s);   // timing probes (tools/attn_bench.py)
