@@ -45,3 +45,15 @@ def test_bench_under_torchrun_launcher():
                         "--rows", "4", "--frames", "10", "--stub"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     _check(_json_line(r.stdout), 2)
+
+
+def test_bench_long_text_mode_stub():
+    """`bench.py --long-text` (BASELINE config 5: 8 rows x 8 chunks, prompt carried over every chunk) runs its chunk loop and
+    reports the concatenated frames; stub engine, no GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--long-text", "--steps", "1", "--warmup", "0", "--stub"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["config"]["rows_per_gpu"] == 8 and j["config"]["frames"] == 563
+    assert abs(j["value"] * j["ms_per_step"] / 1e3 - 8 * 8 * 563 / 75.0) < 1.0          # 8 rows x 8 chunks x 563 frames of audio

@@ -63,6 +63,28 @@ def test_kv_cache_matches_fresh_prefill_full_model():
     assert int(np.argmax(cached)) == int(np.argmax(fresh))
 
 
+def test_kv_cache_matches_fresh_prefill_at_long_context():
+    """BASELINE config 5 regime (long-text mode: the previous chunk's ~560 frames are the prompt): after 500 cached decode steps on
+    top of S = 200, Tp = 600 the context is ~1300; the logits must equal those of a fresh prefill whose prompt already holds the
+    500 frames (two different kernel sets: decode vs full-sequence), and dec_attn walked contexts 800 .. 1300 on the way."""
+    m = get_model(12, 0, 0.0, max_new=512, max_prompt=1152, max_text=256, max_batch=2)
+    eng = m.engine
+    a, t = synth.synth_prompt(600, 100, seed=4321)
+    text = np.concatenate([t[0], synth.synth_text(100, 4321)])
+    r = dict(text=text, prompt=a[0], enroll=100, prompt_language="en", text_language="en")
+    k = 500
+    forced = np.random.default_rng(7).integers(0, 1024, size=k)
+    eng.ar_prefill(m.make_batch([r]))
+    for i in range(k):
+        eng.ar_step(np.array([forced[i]], np.int32))
+    cached = eng.ar_logits()[0]
+    ext = np.concatenate([r["prompt"], np.repeat(forced[:, None], 8, axis=1)], axis=0)         # Tp = 1100
+    eng.ar_prefill(m.make_batch([dict(r, prompt=ext)]))
+    fresh = eng.ar_logits()[0]
+    np.testing.assert_allclose(cached, fresh, atol=3e-4, rtol=0)
+    assert int(np.argmax(cached)) == int(np.argmax(fresh))
+
+
 def test_stop_rules_lengths():
     m = get_model(2, 1, 1.0, max_new=320, max_prompt=400, max_text=256)
     a, t = synth.synth_prompt(10, 3, seed=2)
