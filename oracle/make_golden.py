@@ -93,6 +93,32 @@ FULL_CASES = {
 }
 FULL_LOGIT_EVERY = 50          # AR logits are stored for steps 0, 50, ..., 550 (+ the forced-EOS step is not stored)
 
+# Shapes and languages of ALL 41 reference presets (presets/*.npz: frames, prompt text ids, lang_code zh 0 / ja 1 / en 2) -- metadata
+# only; the prompt CONTENT of these cases is synthetic (any ids 0..1023 exercise the same code).  Covers prompts from 161 to 758
+# frames and 18 to 160 prompt text ids in the three prompt languages, each with a different text language.
+PRESET_SHAPES = [
+    ("acou_1", 225, 58, 2), ("acou_2", 225, 30, 2), ("acou_3", 225, 28, 2), ("acou_4", 225, 40, 2), ("alan", 749, 160, 1),
+    ("amused", 310, 32, 2), ("anger", 324, 71, 2), ("babara", 162, 46, 0), ("bronya", 265, 45, 0), ("cafe", 331, 59, 1),
+    ("dingzhen", 263, 67, 0), ("disgust", 596, 57, 2), ("emo_amused", 225, 24, 2), ("emo_anger", 225, 31, 2),
+    ("emo_neutral", 225, 49, 2), ("emo_sleepy", 225, 23, 2), ("emotion_sleepiness", 500, 54, 2), ("en2zh_tts_1", 663, 142, 2),
+    ("en2zh_tts_2", 361, 36, 2), ("en2zh_tts_3", 313, 74, 2), ("en2zh_tts_4", 654, 148, 2), ("esta", 602, 117, 1),
+    ("fuxuan", 758, 129, 1), ("librispeech_1", 225, 58, 2), ("librispeech_2", 225, 29, 2), ("librispeech_3", 225, 56, 2),
+    ("librispeech_4", 225, 51, 2), ("neutral", 308, 69, 2), ("paimon", 198, 38, 0), ("rosalia", 161, 40, 0), ("seel", 191, 68, 0),
+    ("sleepiness", 500, 54, 2), ("vctk_1", 225, 43, 2), ("vctk_2", 225, 34, 2), ("vctk_3", 225, 33, 2), ("vctk_4", 225, 18, 2),
+    ("yaesakura", 177, 41, 0), ("zh2en_tts_1", 345, 85, 0), ("zh2en_tts_2", 294, 71, 0), ("zh2en_tts_3", 258, 76, 0),
+    ("zh2en_tts_4", 500, 112, 0),
+]
+PRESET_SHAPE_SEED, PRESET_SHAPE_FRAMES = 21, 10
+
+
+def preset_shape_case(i):
+    """case dict (same schema as CASES) of preset-shape i: 2 layers, greedy, 12 text ids, forced EOS at 10 frames"""
+    name, tp, sp, code = PRESET_SHAPES[i]
+    return dict(num_layers=2, seed=PRESET_SHAPE_SEED, eos_gain=0.0, synth_prompt=(tp, sp), prompt_seed=500 + i, n_text=12,
+                text_seed=700 + i, lang=("en", "zh", "ja")[i % 3], prompt_lang=CODE2LANG[code], top_k=1,
+                force_eos_at=PRESET_SHAPE_FRAMES, useed=None)
+
+
 # VALLE.continual (models/vallex.py:688-787): text ids + a full (T, 8) code matrix; NAR stages only
 CONTINUAL_CASES = {
     "nl2_continual": dict(num_layers=2, seed=6, eos_gain=1.0, n_text=14, frames=61),          # prefix_len = 30
@@ -111,7 +137,7 @@ def case_inputs(c):
     if "preset" in c:
         a, t, pl = load_preset(c["preset"])
     else:
-        a, t = synth.synth_prompt(*c["synth_prompt"], seed=c["seed"])
+        a, t = synth.synth_prompt(*c["synth_prompt"], seed=c.get("prompt_seed", c["seed"]))
         pl = c["prompt_lang"]
     txt = synth.synth_text(c["n_text"], c.get("text_seed", c["seed"]))[None]
     text = np.concatenate([t, txt], -1)
@@ -230,8 +256,23 @@ def run_reference_continual(c):
     return dict(codes=codes.numpy().astype(np.int64))
 
 
+def make_preset_shapes():
+    """one fixture for all 41 preset shapes: codes [41][10][8] + the first AR logits row of each"""
+    codes, logits = [], []
+    for i in range(len(PRESET_SHAPES)):
+        out = run_reference(preset_shape_case(i))
+        assert out["codes"].shape == (1, PRESET_SHAPE_FRAMES, 8), (PRESET_SHAPES[i], out["codes"].shape)
+        codes.append(out["codes"][0].astype(np.int16))
+        logits.append(out["ar_logits"][0])
+        print(PRESET_SHAPES[i], out["codes"][0, :3, 0], flush=True)
+    np.savez_compressed(os.path.join(GOLD, "preset_shapes.npz"), codes=np.stack(codes), ar_logits0=np.stack(logits).astype(np.float32))
+
+
 def main(only=None):
     os.makedirs(GOLD, exist_ok=True)
+    if only and "preset_shapes" in only:
+        make_preset_shapes()
+        return
     for name, c in CONTINUAL_CASES.items():
         if only and name not in only:
             continue

@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 from oracle import synth
-from oracle.make_golden import CASES, CONTINUAL_CASES, SHARP_CASES, case_inputs, continual_inputs
+from oracle.make_golden import (CASES, CONTINUAL_CASES, PRESET_SHAPES, SHARP_CASES, case_inputs, continual_inputs,
+                                preset_shape_case)
 from oracle.vallex_oracle import VallexOracle, VocosOracle
 from tests._util import case_row, get_model, golden
 
@@ -77,6 +78,26 @@ def test_infer_matches_reference_tokens(name):
     g = golden(name)["codes"]
     assert tuple(out.shape) == g.shape
     np.testing.assert_array_equal(out.numpy(), g)
+
+
+def test_all_41_preset_shapes_match_reference():
+    """prompt shapes and languages of every reference preset (161..758 frames, 18..160 prompt text ids, zh/ja/en prompts with a
+    different text language each): bit-exact ids against the live reference, each row alone AND all 41 in one call (two
+    micro-batches of the engine, ragged lengths)."""
+    g = golden("preset_shapes")
+    c0 = preset_shape_case(0)
+    m = get_model(c0["num_layers"], c0["seed"], c0["eos_gain"], max_new=64, max_prompt=800, max_text=256, max_batch=41)
+    rows = []
+    for i in range(len(PRESET_SHAPES)):
+        c = preset_shape_case(i)
+        a, t, text, pl, langs = case_inputs(c)
+        rows.append(dict(text=text[0], prompt=a[0], enroll=t.shape[-1], prompt_language=pl, text_language=langs))
+    for i in (0, 4, 9, 22, 29, 40):
+        out = m.inference_batch([rows[i]], top_k=1, force_eos_at=c0["force_eos_at"])[0]
+        np.testing.assert_array_equal(out, g["codes"][i].astype(np.int64), err_msg=PRESET_SHAPES[i][0])
+    outs = m.inference_batch(rows, top_k=1, force_eos_at=c0["force_eos_at"])
+    for i, o in enumerate(outs):
+        np.testing.assert_array_equal(o, g["codes"][i].astype(np.int64), err_msg=PRESET_SHAPES[i][0])
 
 
 def test_infer_12_layers_matches_reference():

@@ -6,8 +6,8 @@ import numpy as np
 import pytest
 
 from oracle import synth
-from oracle.make_golden import (CASES, CONTINUAL_CASES, FULL_CASES, FULL_LOGIT_EVERY, GOLD, SHARP_CASES, case_inputs,
-                                continual_inputs)
+from oracle.make_golden import (CASES, CONTINUAL_CASES, FULL_CASES, FULL_LOGIT_EVERY, GOLD, PRESET_SHAPES, SHARP_CASES,
+                                case_inputs, continual_inputs, preset_shape_case)
 from oracle.vallex_oracle import VallexOracle
 
 FAST = [n for n in CASES if n.startswith("nl2_")]
@@ -108,3 +108,23 @@ def test_oracle_matches_reference_full_length(name):
     assert len(ar) >= 12
     for st in range(7):
         np.testing.assert_allclose(taps["nar_logits"][st][:16].numpy(), g["nar_logits"][st], atol=5e-3, rtol=0)
+
+
+def test_oracle_matches_reference_on_preset_shapes():
+    """the shapes / languages of the reference's 41 presets (metadata only, synthetic content): oracle ids == live reference ids.
+    A spread of 9 by default (shortest, longest, every language), all 41 with VX_SLOW=1."""
+    g = np.load(os.path.join(GOLD, "preset_shapes.npz"))
+    assert g["codes"].shape == (len(PRESET_SHAPES), 10, 8)
+    pick = range(len(PRESET_SHAPES)) if os.environ.get("VX_SLOW") == "1" else (0, 4, 7, 9, 17, 22, 29, 35, 40)
+    orc = None
+    for i in pick:
+        c = preset_shape_case(i)
+        if orc is None:
+            orc = VallexOracle(synth.vallex_state_dict(c["num_layers"], c["seed"], c["eos_gain"]), c["num_layers"])
+        a, t, text, pl, langs = case_inputs(c)
+        assert a.shape[1] == PRESET_SHAPES[i][1] and t.shape[1] == PRESET_SHAPES[i][2]
+        taps = {}
+        codes = orc.inference(text, np.array([text.shape[-1]]), a, t.shape[-1], top_k=1, prompt_language=pl, text_language=langs,
+                              force_eos_at=c["force_eos_at"], taps=taps)
+        np.testing.assert_array_equal(codes[0], g["codes"][i].astype(np.int64), err_msg=PRESET_SHAPES[i][0])
+        np.testing.assert_allclose(taps["ar_logits"][0].numpy(), g["ar_logits0"][i], atol=2e-4, rtol=0)
