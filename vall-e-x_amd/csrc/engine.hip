@@ -865,10 +865,15 @@ int vx_finalize_weights(vx_ctx* c) {
   c->gen_stride = c->cfg.max_new;
   const long M = c->Mmax + 128;
   if ((e = dev_alloc(c, &c->fx, (size_t)M * d))) return e;
+  // kernel selection (read once per context): the defaults are the measured best
+  if (const char* ev = getenv("VX_GEMM_X3")) if (ev[0] == '1') c->gemm_mode = 1;
+  if (const char* ev = getenv("VX_GEMM_F32")) if (ev[0] == '1') c->gemm_mode = 2;
+  if (const char* ev = getenv("VX_ATTN_F32")) c->attn_x3 = !(ev[0] == '1');
   if ((e = dev_alloc(c, &c->fxn, (size_t)M * d))) return e;
   if ((e = dev_alloc(c, &c->fqkv, (size_t)M * 3 * d))) return e;
-  if ((e = dev_alloc(c, &c->fatt, (size_t)M * d))) return e;
-  if ((e = dev_alloc(c, &c->fffn, (size_t)M * f))) return e;
+  // in f16x2 mode the attention output and the FFN hidden activations only ever exist as operand planes (fa3 / fa3b)
+  if (!(c->gemm_mode == 0 && c->attn_x3) && (e = dev_alloc(c, &c->fatt, (size_t)M * d))) return e;
+  if (c->gemm_mode != 0 && (e = dev_alloc(c, &c->fffn, (size_t)M * f))) return e;
   if ((e = dev_alloc(c, &c->fyemb, (size_t)M * d))) return e;
   if ((e = dev_alloc(c, &c->flogits, (size_t)((long)c->mbr * c->cfg.max_new + 128) * AUDIO_VOCAB))) return e;
   c->imeta_cap = std::max(M * 24, (long)c->cfg.max_batch * c->cfg.max_new * 12) + 65536;
@@ -920,9 +925,6 @@ int vx_finalize_weights(vx_ctx* c) {
   }
 
   // ---- 16-bit operand planes of every transformer projection used on the full-sequence paths ----
-  if (const char* ev = getenv("VX_GEMM_X3")) if (ev[0] == '1') c->gemm_mode = 1;
-  if (const char* ev = getenv("VX_GEMM_F32")) if (ev[0] == '1') c->gemm_mode = 2;
-  if (const char* ev = getenv("VX_ATTN_F32")) c->attn_x3 = !(ev[0] == '1');
   if ((e = dev_alloc(c, &c->range_flag, 1))) return e;
   if (c->gemm_mode != 2) {
     const int P = c->gemm_mode == 0 ? 2 : 3;
