@@ -157,3 +157,48 @@ def test_hip_encoder_matches_transformers_port():
         emb = orc.embeddings(wav).numpy()
         ties = sum(_codes_agree_up_to_ties(got[b], gold[b], emb[b], dec) for b in range(got.shape[0]))
         assert ties <= max(1, gold.shape[0] * gold.shape[1] // 10), ties  # a few near-ties at most
+
+
+@pytest.mark.gpu
+def test_make_prompt_writes_a_reference_format_preset(tmp_path):
+    """prompt enrolment end to end (utils/prompt_making.py:57-84): waveform -> EnCodec encoder + RVQ on the GPU -> .npz in the
+    reference's wire format -> usable as `prompt=` of generate_audio."""
+    from scipy.io import wavfile
+    from oracle import synth
+    from vallex_amd.utils import generation as G
+    from vallex_amd.utils import prompt_making as PM
+    dec = encodec_state_dict(3)
+    sd = dict(dec)
+    sd.update(encodec_encoder_state_dict(4))
+    G.preload_models(state_dict=synth.vallex_state_dict(2, 11), vocos_state_dict=synth.vocos_state_dict(2), num_layers=2, max_new=64,
+                     max_prompt=128, max_text=64, max_batch=2)
+    G.model.load_encodec_state_dict(sd)
+    PM.codec = None
+    G.language_detector = lambda text: "en"
+    G.text_tokenizer = lambda text: ([5 + (ord(ch) % 60) for ch in text], ["en"] * len(text))
+    try:
+        rng = np.random.default_rng(3)
+        wav = (0.1 * rng.standard_normal((2, 7777))).astype(np.float32)                    # stereo, not a multiple of the hop
+        path = PM.make_prompt("unit", (wav, 24000), transcript="hello there", save_dir=str(tmp_path))
+        d = np.load(path)
+        T = -(-7777 // 320)
+        assert d["audio_tokens"].shape == (1, T, 8) and d["audio_tokens"].min() >= 0 and d["audio_tokens"].max() < 1024
+        assert d["text_tokens"].shape == (1, len("[EN]hello there[EN]")) and int(d["lang_code"]) == 2
+        # the same codes as encoding the mono mix directly
+        tok = AudioTokenizer(device="cuda:0", valle=G.model)
+        direct = np.asarray(tok.encode(wav.mean(0, keepdims=True)[None])[0][0])
+        np.testing.assert_array_equal(np.transpose(direct, (0, 2, 1)), d["audio_tokens"])
+        # a WAV file on disk gives the same preset (16-bit PCM round trip aside: use float WAV)
+        wavfile.write(str(tmp_path / "p.wav"), 24000, wav.T)
+        d2 = np.load(PM.make_prompt("unit2", str(tmp_path / "p.wav"), transcript="hello there", save_dir=str(tmp_path)))
+        np.testing.assert_array_equal(d2["audio_tokens"], d["audio_tokens"])
+        # and it drops into generate_audio
+        out = G.generate_audio(synth.synth_text(6, 1), prompt=path, language="en", uniforms=synth.uniforms(32, 1, 5)[:, 0], force_eos_at=8)
+        assert out.shape == (8 * 320,) and np.isfinite(out).all()
+        with pytest.raises(ValueError, match="too long"):
+            PM.make_prompt("long", (np.zeros((1, 24000 * 16), np.float32), 24000), transcript="x", save_dir=str(tmp_path))
+        with pytest.raises(NotImplementedError):
+            PM.make_prompt("sr", (np.zeros((1, 16000), np.float32), 16000), transcript="x", save_dir=str(tmp_path))
+    finally:
+        G.language_detector = None
+        G.text_tokenizer = None
