@@ -50,16 +50,9 @@ void launch_pack_weight(const float* W, int N, int K, float* Wp, int Npad, hipSt
 // skinny GEMM: partial[ks][b][n] = sum_{k in slice ks} x[b][k] * W[n][k]
 // grid = (Npad/32, splitk); 4 waves split the block's K slice and reduce through LDS.
 // ------------------------------------------------------------------------------------------------------------
-// OUT 0: raw split-K partial slab [ks][b][n] (row-major per batch row; consumers: dec_attn, dec_reduce_ln_pack, sample)
-// OUT 1: raw split-K partial slab in the PACKED-x image of the next GEMM (whose k is this GEMM's n):
-//        out[ks][((nt*4 + g4)*64 + lane)*4 + j] -- one coalesced 1-KiB store per g4
-// XIN 0: x fragment = packed image as is
-// XIN 1: x fragment = relu(x0 + x1 + bias[k])  with x1 = x0 + xslab floats: the producer was an OUT-1 GEMM with split-K 2
-//        (linear1's bias + ReLU, modules/transformer.py:371-373, folded into linear2's operand load)
-template <int OUT, int XIN>
+// output: raw split-K partial slab [ks][b][n] (row-major per batch row; consumers: dec_attn, dec_reduce_ln_pack, dec_sample)
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restrict__ Wp, const float* __restrict__ xp,
-                                                          float* __restrict__ out, const float* __restrict__ xbias,
-                                                          long xslab, int Npad, int K, int splitk,
+                                                          float* __restrict__ out, int Npad, int K, int splitk,
                                                           const int* __restrict__ n_active) {
   __shared__ __attribute__((aligned(16))) float red[3 * 16 * 64];
   if (n_active && *n_active == 0) return;          // every row has finished: the rest of this step is a no-op
@@ -80,15 +73,6 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
     // x first: it is L2-resident and returns early, so the MFMAs can start as soon as the first weight tile lands
 #pragma unroll
     for (int u = 0; u < 8; ++u) x[u] = xq[(long)(i + u) * 64];
-    if (XIN == 1) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const f32x4 x1 = *(reinterpret_cast<const f32x4*>(xp + xslab) + (long)(kb0 + i + u) * 64 + lane);
-        const f32x4 bi = *reinterpret_cast<const f32x4*>(xbias + (kb0 + i + u) * 8 + 4 * (lane >> 5));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x[u][e] = fmaxf((x[u][e] + x1[e]) + bi[e], 0.f);
-      }
-    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + (long)(i + u) * 64);
 #pragma unroll
@@ -108,28 +92,18 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
     for (int w2 = 0; w2 < 3; ++w2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] += red[(w2 * 16 + r) * 64 + lane];
-    if (OUT == 0) {
-      float* dst = out + ((long)ks * MB + (lane & 31)) * Npad + nt * 32 + 4 * (lane >> 5);
+    float* dst = out + ((long)ks * MB + (lane & 31)) * Npad + nt * 32 + 4 * (lane >> 5);
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        f32x4 t = {acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]};
-        *reinterpret_cast<f32x4*>(dst + g4 * 8) = t;
-      }
-    } else {
-      float* dst = out + (long)ks * MB * Npad;
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        f32x4 t = {acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]};
-        *reinterpret_cast<f32x4*>(dst + (((long)(nt * 4 + g4) * 64) + lane) * 4) = t;
-      }
+    for (int g4 = 0; g4 < 4; ++g4) {
+      f32x4 t = {acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]};
+      *reinterpret_cast<f32x4*>(dst + g4 * 8) = t;
     }
   }
 }
 
 void launch_skinny_gemm(const float* Wp, const float* xp, float* partial, int Npad, int K, int splitk,
                         const int* n_active, hipStream_t s) {
-  hipLaunchKernelGGL((skinny_gemm_kernel<0, 0>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, xp, partial, nullptr,
-                     0L, Npad, K, splitk, n_active);
+  hipLaunchKernelGGL(skinny_gemm_kernel, dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, xp, partial, Npad, K, splitk, n_active);
 }
 
 // ------------------------------------------------------------------------------------------------------------
