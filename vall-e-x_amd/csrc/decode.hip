@@ -355,28 +355,37 @@ constexpr int ATT_STRIDE = ATT_WAVES * 4 * ATT_U;   // rows consumed per block i
 // wo_heads[((h * 16 + d/4) * 1024 + n) * 4 + d%4], so a wave reads 1 KiB runs; a head's 256 KiB slice is shared by the 32
 // row-workgroups of that head, which all run on XCDs h % 8 (block id % 8) and find it in that XCD's L2.  This removes one
 // weight-streaming launch + kernel boundary per layer from the latency chain of the step.
+// The fused variant runs TWO rows of the same head per workgroup (16 waves: waves 0-7 stream launch slot y, waves 8-15 slot
+// y + ceil(batch/2) -- with the engine's row order a long and a short context), so the head's 256 KiB W_o slice, whose
+// L2 -> CU read (64 B/clk per CU) is what the epilogue costs, is read once per two rows.
 template <bool FUSE_OUT>
-__global__ __launch_bounds__(ATT_WAVES * 64, 4) void dec_attn_kernel(const float* __restrict__ qkv_partial, int splitk,
-                                                                     const float* __restrict__ qkv_bias,
-                                                                     float* __restrict__ kc, float* __restrict__ vc,
-                                                                     int Tmax, const int* __restrict__ ctx_len,
-                                                                     const int* __restrict__ active,
-                                                                     float* __restrict__ xp_out,
-                                                                     float* __restrict__ part_o,
-                                                                     float* __restrict__ part_ml, int nsplit,
-                                                                     const float* __restrict__ wo_heads,
-                                                                     float* __restrict__ out_heads,
-                                                                     const int* __restrict__ row_order) {
-  __shared__ __attribute__((aligned(16))) float sh_o[ATT_WAVES][64];
-  __shared__ __attribute__((aligned(16))) float sh_ot[64];
-  __shared__ float sh_m[ATT_WAVES], sh_l[ATT_WAVES];
-  // row_order: launch slot -> batch row.  Workgroups are dispatched in block-id order, two per CU, so slot y and slot
-  // y + batch/2 share a CU: the engine orders the rows so that the long contexts sit in the first half and each is
-  // paired with a short one (ragged batches: every CU streams about the same number of KV bytes).
-  const int h = blockIdx.x, b = row_order ? row_order[blockIdx.y] : blockIdx.y, sp = blockIdx.z;
-  if (!active[b]) return;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
-  const int ctx = ctx_len[b];                 // cached rows INCLUDING the new token (at ctx-1)
+__global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_attn_kernel(
+    const float* __restrict__ qkv_partial, int splitk, const float* __restrict__ qkv_bias, float* __restrict__ kc,
+    float* __restrict__ vc, int Tmax, const int* __restrict__ ctx_len, const int* __restrict__ active,
+    float* __restrict__ xp_out, float* __restrict__ part_o, float* __restrict__ part_ml, int nsplit,
+    const float* __restrict__ wo_heads, float* __restrict__ out_heads, const int* __restrict__ row_order, int batch) {
+  constexpr int NR = FUSE_OUT ? 2 : 1;        // rows per workgroup
+  __shared__ __attribute__((aligned(16))) float sh_o[NR][ATT_WAVES][64];
+  __shared__ __attribute__((aligned(16))) float sh_ot[NR][64];
+  __shared__ float sh_m[NR][ATT_WAVES], sh_l[NR][ATT_WAVES];
+  __shared__ int sh_live[NR];
+  // row_order: launch slot -> batch row.  The engine orders the rows so that the long contexts sit in the first half of
+  // the slots and slot y + ceil(batch/2) holds a short one: unfused, the two share a CU (workgroups are dispatched in
+  // block-id order, two per CU); fused, they share a workgroup.  Either way every CU streams about the same KV bytes.
+  const int r = FUSE_OUT ? (int)(threadIdx.x >> 9) : 0;
+  const int slot = FUSE_OUT ? (int)blockIdx.y + r * (int)gridDim.y : (int)blockIdx.y;
+  const bool valid = slot < batch;
+  const int h = blockIdx.x, b = valid ? (row_order ? row_order[slot] : slot) : 0, sp = blockIdx.z;
+  const bool live = valid && active[b] != 0;
+  if (!FUSE_OUT) {
+    if (!live) return;
+  } else {
+    if ((threadIdx.x & 511) == 0) sh_live[r] = live;
+    __syncthreads();
+    if (!sh_live[0] && !sh_live[NR - 1]) return;          // uniform over the workgroup
+  }
+  const int lane = threadIdx.x & 63, wid = (threadIdx.x >> 6) & (ATT_WAVES - 1), g = lane >> 4, c = lane & 15;
+  const int ctx = live ? ctx_len[b] : 1;      // cached rows INCLUDING the new token (at ctx-1); a dead half streams nothing
   const int npast = ctx - 1;
   const long head_base = ((long)(b * N_HEAD + h) * Tmax) * D_HEAD;
   const f32x4* kp = reinterpret_cast<const f32x4*>(kc + head_base) + c;
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 4) void dec_attn_kernel(const float
 #pragma unroll
     for (int e = 0; e < 4; ++e) { q4[e] = (q4[e] + b0[e]) * 0.125f; k4[e] += b1[e]; v4[e] += b2[e]; }
   }
-  if (sp == 0 && wid == 0 && g == 0) {        // in-place append: present = (k, v) (modules/activation.py:151-157)
+  if (live && sp == 0 && wid == 0 && g == 0) {        // in-place append: present = (k, v) (modules/activation.py:151-157)
     *reinterpret_cast<f32x4*>(kc + head_base + (long)npast * D_HEAD + c * 4) = k4;
     *reinterpret_cast<f32x4*>(vc + head_base + (long)npast * D_HEAD + c * 4) = v4;
   }
@@ -468,13 +477,14 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 4) void dec_attn_kernel(const float
   }
 #undef ATT_LOAD
 #undef ATT_CONSUME
-  // fused out_proj: the first half of this thread's W_o values (n = tid, all 64 d of the head) is requested now -- it
-  // does not depend on the attention result and its L2 latency hides under the group / wave combine below
-  f32x4 wo[16];
-  const f32x4* wh = reinterpret_cast<const f32x4*>(wo_heads) + (long)h * 16 * D_MODEL + threadIdx.x;
+  // fused out_proj: the first half of this thread's W_o values (n = tid, d < 32 of the head) is requested now -- it does
+  // not depend on the attention result and its L2 latency hides under the group / wave combine below; the second half
+  // is requested after the combine, when the streaming registers are free
+  f32x4 wo[8], wo2[8];
+  const f32x4* wh = reinterpret_cast<const f32x4*>(wo_heads) + (long)h * 16 * D_MODEL + threadIdx.x;   // n = tid (< 1024)
   if (FUSE_OUT) {
 #pragma unroll
-    for (int dg = 0; dg < 16; ++dg) wo[dg] = wh[dg * D_MODEL];
+    for (int dg = 0; dg < 8; ++dg) wo[dg] = wh[dg * D_MODEL];
   }
   // the new token itself (always visible: last mask row is all False, models/vallex.py:535-549)
   if (sp == nsplit - 1 && wid == 0 && g == 0) {
@@ -502,21 +512,21 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 4) void dec_attn_kernel(const float
     m = mn;
   }
   if (g == 0) {
-    *reinterpret_cast<f32x4*>(&sh_o[wid][c * 4]) = o;
-    if (c == 0) { sh_m[wid] = m; sh_l[wid] = l; }
+    *reinterpret_cast<f32x4*>(&sh_o[r][wid][c * 4]) = o;
+    if (c == 0) { sh_m[r][wid] = m; sh_l[r][wid] = l; }
   }
   __syncthreads();
   if (wid == 0 && g == 0) {
     float mt = NEG_BIG;
 #pragma unroll
-    for (int w = 0; w < ATT_WAVES; ++w) mt = fmaxf(mt, sh_m[w]);
+    for (int w = 0; w < ATT_WAVES; ++w) mt = fmaxf(mt, sh_m[r][w]);
     float lt = 0.f;
     f32x4 ot = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < ATT_WAVES; ++w) {
-      const float a = expf(sh_m[w] - mt);
-      lt += sh_l[w] * a;
-      const f32x4 ow = *reinterpret_cast<const f32x4*>(&sh_o[w][c * 4]);
+      const float a = expf(sh_m[r][w] - mt);
+      lt += sh_l[r][w] * a;
+      const f32x4 ow = *reinterpret_cast<const f32x4*>(&sh_o[r][w][c * 4]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) ot[e] += ow[e] * a;
     }
@@ -524,7 +534,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 4) void dec_attn_kernel(const float
       const float inv = 1.0f / lt;
 #pragma unroll
       for (int e = 0; e < 4; ++e) ot[e] *= inv;
-      if (FUSE_OUT) *reinterpret_cast<f32x4*>(&sh_ot[c * 4]) = ot;
+      if (FUSE_OUT) *reinterpret_cast<f32x4*>(&sh_ot[r][c * 4]) = ot;
       // column k = h*64 + 4c: kb = h*8 + (c>>1), hi = c&1
       else *reinterpret_cast<f32x4*>(xp_out + (((long)(h * 8 + (c >> 1)) * 64) + b + 32 * (c & 1)) * 4) = ot;
     } else {
@@ -534,24 +544,34 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 4) void dec_attn_kernel(const float
     }
   }
   if (FUSE_OUT) {
+#pragma unroll
+    for (int dg = 0; dg < 8; ++dg) wo2[dg] = wh[(8 + dg) * D_MODEL];
     __syncthreads();
-    float* dst = out_heads + ((long)h * MB + b) * D_MODEL + threadIdx.x;
+    float acc[NR];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      float acc = 0.f;
+    for (int rr = 0; rr < NR; ++rr) acc[rr] = 0.f;
 #pragma unroll
-      for (int dg = 0; dg < 16; ++dg) {
-        const f32x4 o4 = *reinterpret_cast<const f32x4*>(&sh_ot[dg * 4]);       // LDS broadcast
-        acc = fmaf(wo[dg][0], o4[0], acc);
-        acc = fmaf(wo[dg][1], o4[1], acc);
-        acc = fmaf(wo[dg][2], o4[2], acc);
-        acc = fmaf(wo[dg][3], o4[3], acc);
+    for (int dg = 0; dg < 16; ++dg) {
+      const f32x4 w4 = dg < 8 ? wo[dg & 7] : wo2[dg & 7];
+#pragma unroll
+      for (int rr = 0; rr < NR; ++rr) {
+        const f32x4 o4 = *reinterpret_cast<const f32x4*>(&sh_ot[rr][dg * 4]);      // LDS broadcast
+        acc[rr] = fmaf(w4[0], o4[0], acc[rr]);
+        acc[rr] = fmaf(w4[1], o4[1], acc[rr]);
+        acc[rr] = fmaf(w4[2], o4[2], acc[rr]);
+        acc[rr] = fmaf(w4[3], o4[3], acc[rr]);
       }
-      if (half == 0) {
+    }
+    // pin: LLVM's Sink pass would otherwise move the FMA chains into the conditional stores below and leave the 32 LDS
+    // reads (128 VGPRs) live above them
 #pragma unroll
-        for (int dg = 0; dg < 16; ++dg) wo[dg] = wh[dg * D_MODEL + ATT_WAVES * 64];   // n = tid + 512
-      }
-      dst[half * ATT_WAVES * 64] = acc;
+    for (int rr = 0; rr < NR; ++rr) asm volatile("" : "+v"(acc[rr]));
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) {
+      if (!sh_live[rr]) continue;
+      const int sl = (int)blockIdx.y + rr * (int)gridDim.y;
+      const int br = row_order ? row_order[sl] : sl;
+      out_heads[((long)h * MB + br) * D_MODEL + threadIdx.x] = acc[rr];
     }
   }
 }
@@ -560,11 +580,13 @@ void launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias
                      const int* ctx_len, const int* active, float* xp_out, float* part_o, float* part_ml, int nsplit,
                      int batch, const float* wo_heads, float* out_heads, const int* row_order, hipStream_t s) {
   if (wo_heads && nsplit == 1)
-    hipLaunchKernelGGL(dec_attn_kernel<true>, dim3(N_HEAD, batch, 1), dim3(ATT_WAVES * 64), 0, s, qkv_partial, splitk,
-                       qkv_bias, kc, vc, Tmax, ctx_len, active, xp_out, part_o, part_ml, 1, wo_heads, out_heads, row_order);
+    hipLaunchKernelGGL(dec_attn_kernel<true>, dim3(N_HEAD, (batch + 1) / 2, 1), dim3(ATT_WAVES * 64 * 2), 0, s, qkv_partial,
+                       splitk, qkv_bias, kc, vc, Tmax, ctx_len, active, xp_out, part_o, part_ml, 1, wo_heads, out_heads,
+                       row_order, batch);
   else
     hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(N_HEAD, batch, nsplit), dim3(ATT_WAVES * 64), 0, s, qkv_partial, splitk,
-                       qkv_bias, kc, vc, Tmax, ctx_len, active, xp_out, part_o, part_ml, nsplit, nullptr, nullptr, row_order);
+                       qkv_bias, kc, vc, Tmax, ctx_len, active, xp_out, part_o, part_ml, nsplit, nullptr, nullptr, row_order,
+                       batch);
 }
 
 // W_o [1024][1024] -> head-major image for the fused out_proj: out[((h*16 + d/4)*1024 + n)*4 + d%4] = W_o[n][64h + d]
