@@ -3,6 +3,7 @@ contiguously, time with barrier + max-over-ranks and gather the results after th
 bench.py with a stub engine (`--stub`: no GPU, nothing measured).  Also the launcher form the driver uses."""
 import json
 import os
+import pytest
 import subprocess
 import sys
 
@@ -47,12 +48,13 @@ def test_bench_under_torchrun_launcher():
     _check(_json_line(r.stdout), 2)
 
 
-def test_bench_long_text_mode_stub():
-    """`bench.py --long-text` (BASELINE config 5: 8 rows x 8 chunks, prompt carried over every chunk) runs its chunk loop and
-    reports the concatenated frames; stub engine, no GPU."""
+@pytest.mark.parametrize("carry", ["always", "coin"])
+def test_bench_long_text_mode_stub(carry):
+    """`bench.py --long-text` (BASELINE config 5: 8 rows x 8 chunks; prompt carried over every chunk, or the reference's
+    per-chunk coin with `--carry coin`) runs its chunk loop and reports the concatenated frames; stub engine, no GPU."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--long-text", "--steps", "1", "--warmup", "0", "--stub"],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--long-text", "--carry", carry, "--steps", "1",
+                        "--warmup", "0", "--stub"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _json_line(r.stdout)
     assert j["config"]["rows_per_gpu"] == 8 and j["config"]["frames"] == 563
