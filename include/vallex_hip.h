@@ -32,7 +32,7 @@ typedef struct vx_ctx vx_ctx;
 /* ABI guard.  Every descriptor struct starts with `struct_size` = sizeof(that struct) as the CALLER compiled it; the library
  * rejects a mismatch with VX_EINVAL instead of reading past the end of a shorter (older) struct.  vx_abi_version() returns
  * VX_ABI_VERSION of the library that was actually loaded, so a binding can check it before the first call. */
-#define VX_ABI_VERSION 2
+#define VX_ABI_VERSION 3
 int32_t vx_abi_version(void);
 
 /* Model/arena geometry.  d_model=1024, 16 heads, FFN 4096, 8 codebooks are fixed by the kernels
@@ -48,6 +48,9 @@ typedef struct vx_config {
   int32_t with_vocos;      /* 1: allocate the Vocos head */
   int32_t debug_taps;      /* 1: keep per-layer activations for vx_read_tap */
   int32_t with_encodec;    /* 1: allocate the EnCodec SEANet decoder arena (needs the "encodec.*" tensors) */
+  uint32_t cu_mask[8];     /* all zero: the context's stream may use every CU.  Otherwise bit i of word i/32 enables CU i
+                              (hipExtStreamCreateWithCUMask): contexts that SHARE one GPU get disjoint CU sets, so the
+                              latency-bound decode of one batch runs beside the matrix-bound NAR stages of another */
 } vx_config;
 
 /* ---- lifetime -------------------------------------------------------------------------------------------

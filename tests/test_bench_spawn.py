@@ -59,3 +59,16 @@ def test_bench_long_text_mode_stub(carry):
     j = _json_line(r.stdout)
     assert j["config"]["rows_per_gpu"] == 8 and j["config"]["frames"] == 563
     assert abs(j["value"] * j["ms_per_step"] / 1e3 - 8 * 8 * 563 / 75.0) < 1.0          # 8 rows x 8 chunks x 563 frames of audio
+
+
+def test_bench_contexts_mode_stub():
+    """`bench.py --contexts 2` (throughput mode: two contexts share a GPU, each with its own batch in flight) runs both
+    worker threads and counts every pass; stub engine, no GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--contexts", "2", "--steps", "2", "--warmup", "1",
+                        "--rows", "4", "--frames", "10", "--stub"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["steps"] == 4 and j["config"]["contexts_per_gpu"] == 2 and j["config"]["rows_in_flight_per_gpu"] == 8
+    assert abs(j["value"] * j["ms_per_step"] * 4 / 1e3 - 2 * 2 * 4 * 10 / 75.0) < 1e-2        # every pass of every context counted
+    assert "not the headline" in j["note"]

@@ -26,7 +26,8 @@ class VallexHipError(RuntimeError):
 class vx_config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("num_layers", C.c_int32), ("max_batch", C.c_int32), ("max_text", C.c_int32),
                 ("max_prompt", C.c_int32), ("max_new", C.c_int32), ("use_graph", C.c_int32),
-                ("with_vocos", C.c_int32), ("debug_taps", C.c_int32), ("with_encodec", C.c_int32)]
+                ("with_vocos", C.c_int32), ("debug_taps", C.c_int32), ("with_encodec", C.c_int32),
+                ("cu_mask", C.c_uint32 * 8)]
 
 
 class vx_batch(C.Structure):
@@ -44,7 +45,7 @@ class vx_sampling(C.Structure):
 
 
 # every symbol include/vallex_hip.h declares (tests/test_abi.py checks the library exports exactly these)
-ABI_VERSION = 2       # VX_ABI_VERSION of include/vallex_hip.h this binding was written against
+ABI_VERSION = 3       # VX_ABI_VERSION of include/vallex_hip.h this binding was written against
 
 SYMBOLS = ["vx_abi_version", "vx_create", "vx_destroy", "vx_last_error", "vx_synchronize", "vx_load_tensor", "vx_finalize_weights",
            "vx_infer", "vx_vocos_decode", "vx_encodec_decode", "vx_encodec_encode", "vx_ar_prefill", "vx_ar_logits", "vx_ar_step",
@@ -132,15 +133,23 @@ class Batch:
                           _ptr(self.prompt_lens, C.c_int32))
 
 
+def cu_partition(n: int, total: int = 256):
+    """CU masks of `n` contexts that share one GPU: contiguous, disjoint blocks of total // n CUs each."""
+    per = total // max(1, n)
+    return [((1 << per) - 1) << (per * i) for i in range(n)] if n > 1 else [0]
+
+
 class Engine:
-    """Owns one vx_ctx (one GPU).  Not thread-safe; create one per device / process."""
+    """Owns one vx_ctx.  Not thread-safe: one host thread per context; contexts are independent.  `cu_mask` (int, bit i = CU i;
+    0 = all) confines the context's stream to a CU subset, for several contexts that share one GPU (`cu_partition`)."""
 
     def __init__(self, device_id: int = 0, num_layers: int = 12, max_batch: int = 32, max_text: int = 512,
                  max_prompt: int = 2048, max_new: int = 2048, use_graph: bool = True, with_vocos: bool = True,
-                 debug_taps: bool = False, with_encodec: bool = False):
+                 debug_taps: bool = False, with_encodec: bool = False, cu_mask: int = 0):
         self.lib = load_library()
+        words = (C.c_uint32 * 8)(*[(int(cu_mask) >> (32 * w)) & 0xFFFFFFFF for w in range(8)])
         self.cfg = vx_config(C.sizeof(vx_config), num_layers, max_batch, max_text, max_prompt, max_new, int(use_graph), int(with_vocos),
-                             int(debug_taps), int(with_encodec))
+                             int(debug_taps), int(with_encodec), words)
         self.ctx = C.c_void_p()
         rc = self.lib.vx_create(device_id, C.byref(self.cfg), C.byref(self.ctx))
         if rc != VX_OK:

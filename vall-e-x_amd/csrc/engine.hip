@@ -746,7 +746,12 @@ int vx_create(int device_id, const vx_config* cfg, vx_ctx** out) {
     return VX_EHIP;
   };
   if ((e = hipSetDevice(device_id)) != hipSuccess) return fail(e, "hipSetDevice");
-  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+  bool masked = false;
+  for (uint32_t w : cfg->cu_mask) masked |= w != 0;
+  if (masked) {      // a context that shares the GPU with others: its stream only dispatches to the CUs of cfg->cu_mask
+    if ((e = hipExtStreamCreateWithCUMask(&c->stream, 8, cfg->cu_mask)) != hipSuccess)
+      return fail(e, "hipExtStreamCreateWithCUMask");
+  } else if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
   for (auto& ev : c->ev_t)
     if ((e = hipEventCreate(&ev)) != hipSuccess) {
       for (auto& e2 : c->ev_t) if (e2) (void)hipEventDestroy(e2);

@@ -115,7 +115,8 @@ class VALLE:
                                 max_prompt=int(kwargs.get("engine_max_prompt", 2048)),   # >= max_new: sliding-window carry-over
                                 max_new=int(kwargs.get("engine_max_new", 2048)),
                                 use_graph=bool(kwargs.get("engine_use_graph", True)),
-                                debug_taps=bool(kwargs.get("engine_debug_taps", False)))
+                                debug_taps=bool(kwargs.get("engine_debug_taps", False)),
+                                cu_mask=int(kwargs.get("engine_cu_mask", 0)))
 
     # ---- nn.Module-ish surface used by the reference's callers --------------------------------------------------
     def to(self, device):
@@ -163,7 +164,8 @@ class VALLE:
                 raise RuntimeError("load_state_dict() first")
             o = self.engine_opts
             eng = Engine(self._device_id, self.num_layers, o["max_batch"], o["max_text"], o["max_prompt"], o["max_new"],
-                         o["use_graph"], self._vocos_sd is not None, o["debug_taps"], self._encodec_sd is not None)
+                         o["use_graph"], self._vocos_sd is not None, o["debug_taps"], self._encodec_sd is not None,
+                         o["cu_mask"])
             for k, v in self._sd.items():
                 eng.load_tensor(k, v)
             tmax = o["max_text"] + o["max_prompt"] + o["max_new"] + 16
