@@ -52,10 +52,10 @@ void launch_pack_weight(const float* W, int N, int K, float* Wp, int Npad, hipSt
 // ------------------------------------------------------------------------------------------------------------
 // output: raw split-K partial slab [ks][b][n] (row-major per batch row; consumers: dec_attn, dec_reduce_ln_pack, dec_sample)
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restrict__ Wp, const float* __restrict__ xp,
-                                                          float* __restrict__ out, int Npad, int K, int splitk,
-                                                          const int* __restrict__ n_active) {
+                                                          float* __restrict__ out, int Npad, int K, int splitk) {
   __shared__ __attribute__((aligned(16))) float red[3 * 16 * 64];
-  if (n_active && *n_active == 0) return;          // every row has finished: the rest of this step is a no-op
+  // (no "every row has finished" early exit here: reading that flag -- written by the previous step's sampler -- costs a
+  // memory round trip before the first weight load of EVERY launch; steps after the last EOS are bounded by sync_every)
   const int nt = blockIdx.x, ks = blockIdx.y;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int KB = K / 8;
@@ -68,18 +68,22 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  for (int i = 0; i < kb_per_wave; i += 8) {
-    f32x4 w[8], x[8];
-    // x first: it is L2-resident and returns early, so the MFMAs can start as soon as the first weight tile lands
-#pragma unroll
-    for (int u = 0; u < 8; ++u) x[u] = xq[(long)(i + u) * 64];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + (long)(i + u) * 64);
+  f32x4 w[8], x[8];
+  // x first: it is L2-resident and returns early, so the MFMAs can start as soon as the first weight tile lands
+#define VX_SK_LOAD(I)                                                                              \
+  _Pragma("unroll") for (int u = 0; u < 8; ++u) x[u] = xq[(long)((I) + u) * 64];                    \
+  _Pragma("unroll") for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + (long)((I) + u) * 64);
+  VX_SK_LOAD(0)
+  for (int i = 0;;) {
 #pragma unroll
     for (int u = 0; u < 8; ++u)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[u][j], x[u][j], acc, 0, 0, 0);
+    i += 8;
+    if (i >= kb_per_wave) break;
+    VX_SK_LOAD(i)
   }
+#undef VX_SK_LOAD
 
   // acc[r] = out[b = lane&31][n = nt*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)]
   if (wid > 0) {
@@ -102,8 +106,8 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
 }
 
 void launch_skinny_gemm(const float* Wp, const float* xp, float* partial, int Npad, int K, int splitk,
-                        const int* n_active, hipStream_t s) {
-  hipLaunchKernelGGL(skinny_gemm_kernel, dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, xp, partial, Npad, K, splitk, n_active);
+                        hipStream_t s) {
+  hipLaunchKernelGGL(skinny_gemm_kernel, dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, xp, partial, Npad, K, splitk);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -137,10 +141,8 @@ constexpr int S16_WAVES = 8;
 __global__ __launch_bounds__(S16_WAVES * 64) void skinny16_relu_pack_kernel(const float* __restrict__ W16,
                                                                             const float* __restrict__ xp,
                                                                             const float* __restrict__ bias,
-                                                                            float* __restrict__ xp_out, int K,
-                                                                            const int* __restrict__ n_active) {
+                                                                            float* __restrict__ xp_out, int K) {
   __shared__ __attribute__((aligned(16))) float red[(S16_WAVES - 1) * 8 * 64];
-  if (n_active && *n_active == 0) return;
   const int nt = blockIdx.x;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int KB = K / 16, per = KB / S16_WAVES;        // K = 1024: 64 k-blocks, 8 per wave
@@ -151,12 +153,12 @@ __global__ __launch_bounds__(S16_WAVES * 64) void skinny16_relu_pack_kernel(cons
   const f32x4* xq = reinterpret_cast<const f32x4*>(xp) + (long)(2 * kb0 + (kg >> 1)) * 64 + bl + 32 * (kg & 1);
 
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  for (int i = 0; i < per; i += 8) {
-    f32x4 w[8], x0[8], x1[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { x0[u] = xq[(long)(i + u) * 128]; x1[u] = xq[(long)(i + u) * 128 + 16]; }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + (long)(i + u) * 64);
+  f32x4 w[8], x0[8], x1[8];
+#define VX_S16_LOAD(I)                                                                                                   \
+  _Pragma("unroll") for (int u = 0; u < 8; ++u) { x0[u] = xq[(long)((I) + u) * 128]; x1[u] = xq[(long)((I) + u) * 128 + 16]; } \
+  _Pragma("unroll") for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + (long)((I) + u) * 64);
+  VX_S16_LOAD(0)
+  for (int i = 0;;) {
 #pragma unroll
     for (int u = 0; u < 8; ++u)
 #pragma unroll
@@ -164,7 +166,11 @@ __global__ __launch_bounds__(S16_WAVES * 64) void skinny16_relu_pack_kernel(cons
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][j], x0[u][j], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][j], x1[u][j], acc1, 0, 0, 0);
       }
+    i += 8;
+    if (i >= per) break;
+    VX_S16_LOAD(i)
   }
+#undef VX_S16_LOAD
   // acc{h}[r] = out[b = 16h + (lane&15)][n = 16nt + 4(lane>>4) + r]
   if (wid > 0) {
 #pragma unroll
@@ -193,9 +199,8 @@ __global__ __launch_bounds__(S16_WAVES * 64) void skinny16_relu_pack_kernel(cons
 }
 
 void launch_skinny16_relu_pack(const float* W16, const float* xp, const float* bias, float* xp_out, int N, int K,
-                               const int* n_active, hipStream_t s) {
-  hipLaunchKernelGGL(skinny16_relu_pack_kernel, dim3(N / 16), dim3(S16_WAVES * 64), 0, s, W16, xp, bias, xp_out, K,
-                     n_active);
+                               hipStream_t s) {
+  hipLaunchKernelGGL(skinny16_relu_pack_kernel, dim3(N / 16), dim3(S16_WAVES * 64), 0, s, W16, xp, bias, xp_out, K);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -440,7 +440,7 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
   // final norm + ar_predict_layer on those rows (models/vallex.py:568)
   launch_dec_reduce_ln_pack(nullptr, 0, D_MODEL, nullptr, c->dh, nullptr, W(c, "ar_decoder.norm.weight"),
                             W(c, "ar_decoder.norm.bias"), c->xp, nb, c->stream);
-  launch_skinny_gemm(c->pred_wp, c->xp, c->p_logits, PRED_NPAD, D_MODEL, SK_PRED, nullptr, c->stream);
+  launch_skinny_gemm(c->pred_wp, c->xp, c->p_logits, PRED_NPAD, D_MODEL, SK_PRED, c->stream);
   if (beams > 1) {
     launch_beam_kv_broadcast(c->kc, c->vc, (long)cache_layer, NL, c->Tmax, seq_len[0], beams, c->stream);
     for (int i = 1; i < beams; ++i) {
@@ -488,7 +488,7 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
                              W(c, "ar_audio_position.alpha"), c->pe, c->dh, c->ar[0].n1_w, c->ar[0].n1_b, c->xp, nb, st);
   for (int l = 0; l < NL; ++l) {
     const LayerW& L = c->ar[l];
-    { ProfScope ps(c, 1); launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, c->n_active, st); }
+    { ProfScope ps(c, 1); launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, st); }
     const bool fused = c->fuse_out && c->nsplit == 1;
     {
       ProfScope ps(c, 0);
@@ -500,16 +500,16 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
       launch_dec_reduce_ln_pack(c->p_oh, N_HEAD, D_MODEL, L.out_b, c->dh, c->dh, L.n2_w, L.n2_b, c->xp, nb, st);
     } else {
       if (c->nsplit > 1) launch_dec_attn_combine(c->part_o, c->part_ml, c->nsplit, c->active, c->xp_att, nb, st);
-      { ProfScope ps(c, 1); launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, c->n_active, st); }
+      { ProfScope ps(c, 1); launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, st); }
       launch_dec_reduce_ln_pack(c->p_o, SK_OUT, D_MODEL, L.out_b, c->dh, c->dh, L.n2_w, L.n2_b, c->xp, nb, st);
     }
-    { ProfScope ps(c, 1); launch_skinny16_relu_pack(L.l1_wp, c->xp, L.l1_b, c->xp4, D_FF, D_MODEL, c->n_active, st); }
-    { ProfScope ps(c, 1); launch_skinny_gemm(L.l2_wp, c->xp4, c->p_o, D_MODEL, D_FF, SK_L2, c->n_active, st); }
+    { ProfScope ps(c, 1); launch_skinny16_relu_pack(L.l1_wp, c->xp, L.l1_b, c->xp4, D_FF, D_MODEL, st); }
+    { ProfScope ps(c, 1); launch_skinny_gemm(L.l2_wp, c->xp4, c->p_o, D_MODEL, D_FF, SK_L2, st); }
     const float* ng = (l + 1 < NL) ? c->ar[l + 1].n1_w : W(c, "ar_decoder.norm.weight");
     const float* nbp = (l + 1 < NL) ? c->ar[l + 1].n1_b : W(c, "ar_decoder.norm.bias");
     launch_dec_reduce_ln_pack(c->p_o, SK_L2, D_MODEL, L.l2_b, c->dh, c->dh, ng, nbp, c->xp, nb, st);
   }
-  { ProfScope ps(c, 1); launch_skinny_gemm(c->pred_wp, c->xp, c->p_logits, PRED_NPAD, D_MODEL, SK_PRED, c->n_active, st); }
+  { ProfScope ps(c, 1); launch_skinny_gemm(c->pred_wp, c->xp, c->p_logits, PRED_NPAD, D_MODEL, SK_PRED, st); }
   if (sa) launch_dec_sample(*sa, st);
 }
 
@@ -558,7 +558,8 @@ int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int 
            sa.uniforms != nullptr, sa.force_eos_at, (unsigned long long)sa.seed, sa.sum_logp != nullptr);
   const int sync_every = s->sync_every > 0 ? s->sync_every : 8;
   std::vector<int> act(nb);
-  const int hard_cap = c->gen_stride + 2;
+  // with a forced EOS every row is inactive after force_eos_at steps: do not run on to the next host poll
+  const int hard_cap = s->force_eos_at >= 0 ? std::min(c->gen_stride + 2, s->force_eos_at) : c->gen_stride + 2;
   int steps = 0;
   bool any = true;
   // was anything left active after the first sample?
@@ -1573,7 +1574,7 @@ int vx_encodec_decode(vx_ctx* c, const int64_t* codes, int32_t codes_stride, con
       HIPCHK(hipMemsetAsync(c->ec_c, 0, (size_t)MB * 512 * sizeof(float), st));
       float* yout = l == 0 ? c->ec_y1 : c->ec_y2;
       for (int t = 0; t < maxT; ++t) {
-        launch_skinny_gemm(c->ec_whh_p[l], c->ec_hp, c->ec_pg, 2048, 512, 2, nullptr, st);
+        launch_skinny_gemm(c->ec_whh_p[l], c->ec_hp, c->ec_pg, 2048, 512, 2, st);
         launch_lstm_cell(c->ec_pg, 2, c->ec_xg, d_off, d_len, t, c->ec_c, c->ec_hp, yout, l == 1 ? c->ec_x0 : nullptr, nb, st);
       }
       lin = yout;
@@ -1691,7 +1692,7 @@ int vx_encodec_encode(vx_ctx* c, const float* wav, int64_t wav_stride, const int
       HIPCHK(hipMemsetAsync(c->ec_c, 0, (size_t)MB * 512 * sizeof(float), st));
       float* yout = l == 0 ? c->ec_y1 : c->ec_y2;
       for (int t = 0; t < maxT; ++t) {
-        launch_skinny_gemm(c->en_whh_p[l], c->ec_hp, c->ec_pg, 2048, 512, 2, nullptr, st);
+        launch_skinny_gemm(c->en_whh_p[l], c->ec_hp, c->ec_pg, 2048, 512, 2, st);
         launch_lstm_cell(c->ec_pg, 2, c->ec_xg, d_off, d_len, t, c->ec_c, c->ec_hp, yout, l == 1 ? c->ec_x0 : nullptr, nb, st);
       }
       lin = yout;
@@ -1801,10 +1802,10 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
   } else if (which == 1) {
     const LayerW& L = c->ar[0];
     auto seq = [&]() {
-      launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, nullptr, c->stream);
-      launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, nullptr, c->stream);
-      launch_skinny16_relu_pack(L.l1_wp, c->xp, L.l1_b, c->xp4, D_FF, D_MODEL, nullptr, c->stream);
-      launch_skinny_gemm(L.l2_wp, c->xp4, c->p_o, D_MODEL, D_FF, SK_L2, nullptr, c->stream);
+      launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, c->stream);
+      launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, c->stream);
+      launch_skinny16_relu_pack(L.l1_wp, c->xp, L.l1_b, c->xp4, D_FF, D_MODEL, c->stream);
+      launch_skinny_gemm(L.l2_wp, c->xp4, c->p_o, D_MODEL, D_FF, SK_L2, c->stream);
     };
     seq();
     HIPCHK(hipEventRecord(e0, c->stream));
@@ -1816,7 +1817,7 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
     // cache-retention probe: the SAME weight-streaming GEMM (layer 0 QKV, 12.6 MB) back to back -- what a launch costs when
     // its weights were read a moment ago (memory-side cache hits) instead of coming cold from HBM (which 1)
     const LayerW& L = c->ar[0];
-    auto one = [&]() { launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, nullptr, c->stream); };
+    auto one = [&]() { launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, c->stream); };
     one();
     HIPCHK(hipEventRecord(e0, c->stream));
     for (int r = 0; r < reps; ++r) one();

@@ -118,15 +118,14 @@ void launch_attn_full_probe(const float* qkv, float* out, const int* seq_off, co
 // packed skinny-GEMM weight image: tiles of 32 n-rows x 8 k, lane-linear (see decode.hip)
 void launch_pack_weight(const float* W, int N, int K, float* Wp, int Npad, hipStream_t s);
 // partial[ks][b][n] = sum_{k in slice ks} x[b][k] * W[n][k];  xp is the packed activation image.
-void launch_skinny_gemm(const float* Wp, const float* xp, float* partial, int Npad, int K, int splitk,
-                        const int* n_active, hipStream_t s);
+void launch_skinny_gemm(const float* Wp, const float* xp, float* partial, int Npad, int K, int splitk, hipStream_t s);
 // h[b] = (resid? resid[b] : 0) + sum_ks partial[ks][b] + bias ; xp = pack(LN(h)*g+b)   (N = 1024)
 void launch_dec_reduce_ln_pack(const float* partial, int splitk, int npad, const float* bias, const float* resid,
                                float* h, const float* g, const float* b, float* xp, int batch, hipStream_t s);
 // linear1 with fused bias+ReLU+pack on 16-row tiles (v_mfma_f32_16x16x4_f32), 256 workgroups, no split-K
 void launch_pack_weight16(const float* W, int N, int K, float* Wp, hipStream_t s);
 void launch_skinny16_relu_pack(const float* W16, const float* xp, const float* bias, float* xp_out, int N, int K,
-                               const int* n_active, hipStream_t s);
+                               hipStream_t s);
 // h[b] = tab[tok[b]] + alpha*pe[pos[b]] ; xp = pack(LN(h))  -- start of a decode step
 void launch_dec_embed_ln_pack(const int* tok, const int* pos, const float* tab, const float* alpha, const float* pe,
                               float* h, const float* g, const float* b, float* xp, int batch, hipStream_t s);
