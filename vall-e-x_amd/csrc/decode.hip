@@ -366,31 +366,37 @@ constexpr int ATT_STRIDE = ATT_WAVES * 4 * ATT_U;   // rows consumed per block i
 template <bool FUSE_OUT>
 __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_attn_kernel(
     const float* __restrict__ qkv_partial, int splitk, const float* __restrict__ qkv_bias, float* __restrict__ kc,
-    float* __restrict__ vc, int Tmax, const int* __restrict__ ctx_len, const int* __restrict__ active,
-    float* __restrict__ xp_out, float* __restrict__ part_o, float* __restrict__ part_ml, int nsplit,
-    const float* __restrict__ wo_heads, float* __restrict__ out_heads, const int* __restrict__ row_order, int batch) {
+    float* __restrict__ vc, int Tmax, const int* __restrict__ slot_meta, float* __restrict__ xp_out,
+    float* __restrict__ part_o, float* __restrict__ part_ml, int nsplit, const float* __restrict__ wo_heads,
+    float* __restrict__ out_heads, int batch) {
   constexpr int NR = FUSE_OUT ? 2 : 1;        // rows per workgroup
   __shared__ __attribute__((aligned(16))) float sh_o[NR][ATT_WAVES][64];
   __shared__ __attribute__((aligned(16))) float sh_ot[NR][64];
   __shared__ float sh_m[NR][ATT_WAVES], sh_l[NR][ATT_WAVES];
-  __shared__ int sh_live[NR];
-  // row_order: launch slot -> batch row.  The engine orders the rows so that the long contexts sit in the first half of
-  // the slots and slot y + ceil(batch/2) holds a short one: unfused, the two share a CU (workgroups are dispatched in
-  // block-id order, two per CU); fused, they share a workgroup.  Either way every CU streams about the same KV bytes.
+  // slot_meta[slot] = {batch row, cached rows incl. the new token, row still active, -}: ONE 16-byte load tells the
+  // workgroup everything it needs before its first K/V load (a slot -> row -> ctx_len / active chain would be two
+  // dependent round trips at the head of every launch).  The engine orders the slots so that the long contexts sit in
+  // the first half and slot y + ceil(batch/2) holds a short one: unfused, the two share a CU (workgroups are dispatched
+  // in block-id order, two per CU); fused, they share a workgroup.  Either way every CU streams about the same KV bytes.
   const int r = FUSE_OUT ? (int)(threadIdx.x >> 9) : 0;
   const int slot = FUSE_OUT ? (int)blockIdx.y + r * (int)gridDim.y : (int)blockIdx.y;
   const bool valid = slot < batch;
-  const int h = blockIdx.x, b = valid ? (row_order ? row_order[slot] : slot) : 0, sp = blockIdx.z;
-  const bool live = valid && active[b] != 0;
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const i32x4 meta = *reinterpret_cast<const i32x4*>(slot_meta + 4 * (valid ? slot : 0));
+  const int h = blockIdx.x, b = meta[0], sp = blockIdx.z;
+  const bool live = valid && meta[2] != 0;
+  bool live_rr[NR];                                       // fused: the state of BOTH halves, the same in every thread
   if (!FUSE_OUT) {
     if (!live) return;
+    live_rr[0] = true;
   } else {
-    if ((threadIdx.x & 511) == 0) sh_live[r] = live;
-    __syncthreads();
-    if (!sh_live[0] && !sh_live[NR - 1]) return;          // uniform over the workgroup
+    const int s1 = (int)blockIdx.y + (int)gridDim.y;
+    live_rr[0] = slot_meta[4 * (int)blockIdx.y + 2] != 0;
+    live_rr[NR - 1] = s1 < batch && slot_meta[4 * (s1 < batch ? s1 : 0) + 2] != 0;
+    if (!live_rr[0] && !live_rr[NR - 1]) return;          // uniform over the workgroup
   }
   const int lane = threadIdx.x & 63, wid = (threadIdx.x >> 6) & (ATT_WAVES - 1), g = lane >> 4, c = lane & 15;
-  const int ctx = live ? ctx_len[b] : 1;      // cached rows INCLUDING the new token (at ctx-1); a dead half streams nothing
+  const int ctx = live ? meta[1] : 1;         // cached rows INCLUDING the new token (at ctx-1); a dead half streams nothing
   const int npast = ctx - 1;
   const long head_base = ((long)(b * N_HEAD + h) * Tmax) * D_HEAD;
   const f32x4* kp = reinterpret_cast<const f32x4*>(kc + head_base) + c;
@@ -573,25 +579,22 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
     for (int rr = 0; rr < NR; ++rr) asm volatile("" : "+v"(acc[rr]));
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
-      if (!sh_live[rr]) continue;
-      const int sl = (int)blockIdx.y + rr * (int)gridDim.y;
-      const int br = row_order ? row_order[sl] : sl;
+      if (!live_rr[rr]) continue;
+      const int br = slot_meta[4 * ((int)blockIdx.y + rr * (int)gridDim.y)];
       out_heads[((long)h * MB + br) * D_MODEL + threadIdx.x] = acc[rr];
     }
   }
 }
 
 void launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias, float* kc, float* vc, int Tmax,
-                     const int* ctx_len, const int* active, float* xp_out, float* part_o, float* part_ml, int nsplit,
-                     int batch, const float* wo_heads, float* out_heads, const int* row_order, hipStream_t s) {
+                     const int* slot_meta, float* xp_out, float* part_o, float* part_ml, int nsplit, int batch,
+                     const float* wo_heads, float* out_heads, hipStream_t s) {
   if (wo_heads && nsplit == 1)
     hipLaunchKernelGGL(dec_attn_kernel<true>, dim3(N_HEAD, (batch + 1) / 2, 1), dim3(ATT_WAVES * 64 * 2), 0, s, qkv_partial,
-                       splitk, qkv_bias, kc, vc, Tmax, ctx_len, active, xp_out, part_o, part_ml, 1, wo_heads, out_heads,
-                       row_order, batch);
+                       splitk, qkv_bias, kc, vc, Tmax, slot_meta, xp_out, part_o, part_ml, 1, wo_heads, out_heads, batch);
   else
     hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(N_HEAD, batch, nsplit), dim3(ATT_WAVES * 64), 0, s, qkv_partial, splitk,
-                       qkv_bias, kc, vc, Tmax, ctx_len, active, xp_out, part_o, part_ml, nsplit, nullptr, nullptr, row_order,
-                       batch);
+                       qkv_bias, kc, vc, Tmax, slot_meta, xp_out, part_o, part_ml, nsplit, nullptr, nullptr, batch);
 }
 
 // W_o [1024][1024] -> head-major image for the fused out_proj: out[((h*16 + d/4)*1024 + n)*4 + d%4] = W_o[n][64h + d]
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
   // row state: every scalar the kernel needs, requested up front (independent loads)
   const bool act = a.active[b] != 0;
   if (!act && !a.logits_out) return;
-  const int ngen = a.n_gen[b], pos = a.cur_pos[b], ctx = a.ctx_len[b], tlen = a.text_len[b];
+  const int ngen = a.n_gen[b], pos = a.cur_pos[b], ctx = a.ctx_len[b], tlen = a.text_len[b], slot = a.slot_of[b];
 
   {
     float t[SPL];
@@ -828,6 +831,7 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
   if (lane == 0) {
     if (stop) {
       a.active[b] = 0;
+      a.slot_meta[4 * slot + 2] = 0;
       if (a.n_active) atomicSub(a.n_active, 1);
     } else {
       a.gen[(long)b * a.gen_stride + ngen] = tok;
@@ -835,6 +839,7 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
       a.cur_tok[b] = tok;
       a.cur_pos[b] = pos + 1;
       a.ctx_len[b] = ctx + 1;
+      a.slot_meta[4 * slot + 1] = ctx + 1;
     }
   }
   if (stop || !a.emb_tab) return;
@@ -873,7 +878,8 @@ void launch_beam_kv_broadcast(float* kc, float* vc, long cache_layer, int layers
 
 // teacher forcing (tests): commit a caller-chosen token exactly like dec_sample would
 __global__ void dec_force_token_kernel(const int* __restrict__ tok, int* cur_tok, int* cur_pos, int* ctx_len,
-                                       int* n_gen, int* gen, int gen_stride, const int* active, int batch) {
+                                       int* n_gen, int* gen, int gen_stride, const int* active, int batch,
+                                       int* slot_meta, const int* __restrict__ slot_of) {
   const int b = threadIdx.x;
   if (b >= batch || !active[b]) return;
   const int ngen = n_gen[b];
@@ -883,12 +889,14 @@ __global__ void dec_force_token_kernel(const int* __restrict__ tok, int* cur_tok
   cur_tok[b] = tok[b];
   cur_pos[b] += 1;
   ctx_len[b] += 1;
+  slot_meta[4 * slot_of[b] + 1] = ctx_len[b];
 }
 
 void launch_dec_force_token(const int* tok, int* cur_tok, int* cur_pos, int* ctx_len, int* n_gen, int* gen,
-                            int gen_stride, const int* active, int batch, hipStream_t s) {
+                            int gen_stride, const int* active, int batch, int* slot_meta, const int* slot_of,
+                            hipStream_t s) {
   hipLaunchKernelGGL(dec_force_token_kernel, dim3(1), dim3(64), 0, s, tok, cur_tok, cur_pos, ctx_len, n_gen, gen,
-                     gen_stride, active, batch);
+                     gen_stride, active, batch, slot_meta, slot_of);
 }
 
 }  // namespace vx

@@ -95,7 +95,7 @@ struct vx_ctx {
   float *d_logits = nullptr, *d_uniforms = nullptr, *sum_logp = nullptr;
   long uniforms_cap = 0;
   int *cur_tok = nullptr, *cur_pos = nullptr, *ctx_len = nullptr, *n_gen = nullptr, *active = nullptr,
-      *text_len = nullptr, *gen = nullptr, *force_tok = nullptr, *n_active = nullptr, *row_order = nullptr;
+      *text_len = nullptr, *gen = nullptr, *force_tok = nullptr, *n_active = nullptr, *slot_meta = nullptr, *slot_of = nullptr;
   int gen_stride = 0;
   int cur_batch = 0;
   int nsplit = 1;
@@ -387,18 +387,24 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
     st_pos[i] = b->prompt_lens[r0 + j]; st_ctx[i] = seq_len[j]; st_S[i] = S_[j];
   }
   // dec_attn launch order (decode.hip): rows by context length, the longest ceil(nb/2) first (descending), then the rest
-  // ascending, so launch slots y and y + nb/2 -- which share a CU -- hold a long and a short context.  The order of the
-  // contexts never changes during generation (every active row grows by one per step).
+  // ascending, so launch slots y and y + nb/2 -- which share a CU or a workgroup -- hold a long and a short context.  The
+  // order of the contexts never changes during generation (every active row grows by one per step).
   std::vector<int> by_len(nrows), st_ord(nrows);
   for (int i = 0; i < nrows; ++i) by_len[i] = i;
-  std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int b2) { return st_ctx[a] > st_ctx[b2]; });
-  {
+  if (c->balance_rows) std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int b2) { return st_ctx[a] > st_ctx[b2]; });
+  if (!c->balance_rows) st_ord = by_len;                          // VX_BALANCE_ROWS=0: batch order
+  else {
     const int first = (nrows + 1) / 2;
     for (int y = 0; y < first; ++y) st_ord[y] = by_len[y];
     for (int y = first; y < nrows; ++y) st_ord[y] = by_len[nrows - 1 - (y - first)];
   }
+  std::vector<int> st_meta(4 * nrows, 0), st_slot(nrows);
+  for (int y = 0; y < nrows; ++y) {
+    st_meta[4 * y] = st_ord[y]; st_meta[4 * y + 1] = st_ctx[st_ord[y]]; st_meta[4 * y + 2] = 1;
+    st_slot[st_ord[y]] = y;
+  }
   const long o_sp = mb.add(st_pos), o_sc = mb.add(st_ctx), o_z = mb.add(st_zero), o_1 = mb.add(st_one), o_sS = mb.add(st_S),
-             o_ord = mb.add(st_ord);
+             o_meta = mb.add(st_meta), o_slot = mb.add(st_slot);
   if (int e = upload_meta(c)) return e;
   const size_t ib = nrows * sizeof(int);
   HIPCHK(hipMemcpyAsync(c->cur_pos, mb.dev(o_sp), ib, hipMemcpyDeviceToDevice, c->stream));
@@ -407,7 +413,8 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
   HIPCHK(hipMemcpyAsync(c->cur_tok, mb.dev(o_z), ib, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->active, mb.dev(o_1), ib, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->text_len, mb.dev(o_sS), ib, hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(c->row_order, mb.dev(o_ord), ib, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->slot_meta, mb.dev(o_meta), 4 * ib, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->slot_of, mb.dev(o_slot), ib, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->n_active, &nrows, sizeof(int), hipMemcpyHostToDevice, c->stream));
   c->cur_batch = nrows;
   // enough (row, head, split) 8-wave workgroups to put >= 2 on every CU; one split (no combine launch) from 32 rows up
@@ -465,7 +472,7 @@ SampleArgs make_sample_args(vx_ctx* c, const vx_sampling* s, int commit, float* 
   a.force_eos_at = s ? s->force_eos_at : -1;
   a.commit = commit;
   a.cur_tok = c->cur_tok; a.cur_pos = c->cur_pos; a.ctx_len = c->ctx_len; a.n_gen = c->n_gen; a.active = c->active;
-  a.n_active = c->n_active;
+  a.n_active = c->n_active; a.slot_meta = c->slot_meta; a.slot_of = c->slot_of;
   a.text_len = c->text_len; a.gen = c->gen; a.gen_stride = c->gen_stride; a.logits_out = logits_out;
   a.sum_logp = (s && s->best_of > 1) ? c->sum_logp : nullptr;
   a.batch = c->cur_batch;
@@ -492,9 +499,8 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
     const bool fused = c->fuse_out && c->nsplit == 1;
     {
       ProfScope ps(c, 0);
-      launch_dec_attn(c->p_qkv, SK_QKV, L.in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax, c->ctx_len,
-                      c->active, c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, fused ? L.out_wh : nullptr, c->p_oh,
-                      c->balance_rows ? c->row_order : nullptr, st);
+      launch_dec_attn(c->p_qkv, SK_QKV, L.in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax, c->slot_meta,
+                      c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, fused ? L.out_wh : nullptr, c->p_oh, st);
     }
     if (fused) {
       launch_dec_reduce_ln_pack(c->p_oh, N_HEAD, D_MODEL, L.out_b, c->dh, c->dh, L.n2_w, L.n2_b, c->xp, nb, st);
@@ -904,8 +910,9 @@ int vx_finalize_weights(vx_ctx* c) {
   c->uniforms_cap = (long)(c->cfg.max_new + 2) * MB;
   if ((e = dev_alloc(c, &c->d_uniforms, (size_t)c->uniforms_cap))) return e;
   for (int** p : {&c->cur_tok, &c->cur_pos, &c->ctx_len, &c->n_gen, &c->active, &c->text_len, &c->force_tok, &c->n_active,
-                  &c->row_order})
+                  &c->slot_of})
     if ((e = dev_alloc(c, p, MB))) return e;
+  if ((e = dev_alloc(c, &c->slot_meta, 4 * MB))) return e;
   if ((e = dev_alloc(c, &c->gen, (size_t)MB * c->gen_stride))) return e;
 
   // ---- positional table, built on the host exactly like modules/embedding.py:75-91 (fp32 ops in the same order) ----
@@ -1318,7 +1325,7 @@ int vx_ar_step(vx_ctx* c, const int32_t* tokens) {
   HIPCHK(hipSetDevice(c->dev));
   HIPCHK(hipMemcpyAsync(c->force_tok, tokens, c->cur_batch * sizeof(int), hipMemcpyHostToDevice, c->stream));
   launch_dec_force_token(c->force_tok, c->cur_tok, c->cur_pos, c->ctx_len, c->n_gen, c->gen, c->gen_stride, c->active,
-                         c->cur_batch, c->stream);
+                         c->cur_batch, c->slot_meta, c->slot_of, c->stream);
   if (int e = ar_step_run(c, nullptr, "")) return e;
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipGetLastError());
@@ -1781,6 +1788,12 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
       bytes += (double)ctx[i] * 2.0 * D_MODEL * 4.0;
     }
     if (c->fuse_out && c->nsplit == 1) bytes += (double)D_MODEL * D_MODEL * 4.0;     // + W_o, streamed once (fused out_proj)
+    // the replay's contexts go into the per-slot view dec_attn reads (the row order of the last prefill is kept)
+    std::vector<int> meta(4 * nb);
+    HIPCHK(hipMemcpyAsync(meta.data(), c->slot_meta, meta.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int y = 0; y < nb; ++y) { meta[4 * y + 1] = ctx[meta[4 * y]]; meta[4 * y + 2] = 1; }
+    HIPCHK(hipMemcpyAsync(c->slot_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->ctx_len, ctx.data(), nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->active, one.data(), nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1790,9 +1803,9 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
     auto attn_l = [&](int r) {
       const int l = r % c->NL;
       const bool fused = c->fuse_out && c->nsplit == 1;
-      launch_dec_attn(c->p_qkv, SK_QKV, c->ar[l].in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax, c->ctx_len,
-                      c->active, c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, fused ? c->ar[l].out_wh : nullptr, c->p_oh,
-                      c->balance_rows ? c->row_order : nullptr, c->stream);
+      launch_dec_attn(c->p_qkv, SK_QKV, c->ar[l].in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax,
+                      c->slot_meta, c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, fused ? c->ar[l].out_wh : nullptr, c->p_oh,
+                      c->stream);
     };
     for (int w = 0; w < 3; ++w) attn_l(w);
     HIPCHK(hipEventRecord(e0, c->stream));

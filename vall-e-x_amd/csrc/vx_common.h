@@ -131,9 +131,11 @@ void launch_dec_embed_ln_pack(const int* tok, const int* pos, const float* tab, 
                               float* h, const float* g, const float* b, float* xp, int batch, hipStream_t s);
 // one-token attention over the cache, per (b, head, split); appends the new k/v (from the QKV partials).
 // wo_heads != null and nsplit == 1: out_proj fused into the epilogue, per-head partial slabs out_heads[h][MB][1024]
+// slot_meta [batch][4] = {row, cached rows incl. the new token, active, -} per launch slot (kept current by dec_sample /
+// dec_force_token through slot_of[row])
 void launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias, float* kc, float* vc, int Tmax,
-                     const int* ctx_len, const int* active, float* xp_out, float* part_o, float* part_ml, int nsplit,
-                     int batch, const float* wo_heads, float* out_heads, const int* row_order, hipStream_t s);
+                     const int* slot_meta, float* xp_out, float* part_o, float* part_ml, int nsplit, int batch,
+                     const float* wo_heads, float* out_heads, hipStream_t s);
 void launch_pack_wo_heads(const float* W, float* out, hipStream_t s);
 void launch_dec_attn_combine(const float* part_o, const float* part_ml, int nsplit, const int* active, float* xp_out,
                              int batch, hipStream_t s);
@@ -145,6 +147,7 @@ struct SampleArgs {
   int force_eos_at;
   int commit;                                      // 0: only reduce (and export) the logits
   int* cur_tok; int* cur_pos; int* ctx_len; int* n_gen; int* active; int* n_active; const int* text_len;
+  int* slot_meta; const int* slot_of;              // dec_attn's per-slot view of (row, ctx_len, active); slot of each row
   int* gen; int gen_stride;                        // generated ids [b][gen_stride]
   float* logits_out;                               // optional [MB][1025] copy of the reduced logits
   float* sum_logp;                                 // optional [MB] running sum of log p(pick) per row (beam selection)
@@ -157,7 +160,8 @@ void launch_dec_sample(const SampleArgs& a, hipStream_t s);
 // best_of: copy row 0's prefilled K/V (L rows per head, every layer) to rows 1 .. beams-1
 void launch_beam_kv_broadcast(float* kc, float* vc, long cache_layer, int layers, int Tmax, int L, int beams, hipStream_t s);
 void launch_dec_force_token(const int* tok, int* cur_tok, int* cur_pos, int* ctx_len, int* n_gen, int* gen,
-                            int gen_stride, const int* active, int batch, hipStream_t s);
+                            int gen_stride, const int* active, int batch, int* slot_meta, const int* slot_of,
+                            hipStream_t s);
 
 // ---- EnCodec SEANet decoder glue (encodec.hip) ----------------------------------------------------------------
 void launch_im2col_seq(const float* x, int C, int k, int mode, int elu, const int* seq_off, const int* seq_len, int R,
