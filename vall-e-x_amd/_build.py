@@ -11,7 +11,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libvallex_hip.so")
 SOURCES = ["gemm_f32.hip", "gemm_f16x2.hip", "gemm_bf16x3.hip", "gemm_bf16x3_dma.hip", "rows.hip", "attn_full.hip", "attn_full_x3.hip", "decode.hip", "vocos.hip", "encodec.hip", "engine.hip"]
 HEADERS = ["vx_common.h", os.path.join("..", "..", "include", "vallex_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+# kernarg preload: the first kernel arguments arrive in SGPRs with the wave instead of through an s_load round trip at the
+# head of every launch (the compiler keeps a compatibility prologue for firmware without the feature)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result",
+         "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def _hipcc() -> str:
