@@ -363,9 +363,9 @@ constexpr int ATT_STRIDE = ATT_WAVES * 4 * ATT_U;   // rows consumed per block i
 // The fused variant runs TWO rows of the same head per workgroup (16 waves: waves 0-7 stream launch slot y, waves 8-15 slot
 // y + ceil(batch/2) -- with the engine's row order a long and a short context), so the head's 256 KiB W_o slice, whose
 // L2 -> CU read (64 B/clk per CU) is what the epilogue costs, is read once per two rows.
-template <bool FUSE_OUT>
+template <bool FUSE_OUT, int SK>
 __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_attn_kernel(
-    const float* __restrict__ qkv_partial, int splitk, const float* __restrict__ qkv_bias, float* __restrict__ kc,
+    const float* __restrict__ qkv_partial, const float* __restrict__ qkv_bias, float* __restrict__ kc,
     float* __restrict__ vc, int Tmax, const int* __restrict__ slot_meta, float* __restrict__ xp_out,
     float* __restrict__ part_o, float* __restrict__ part_ml, int nsplit, const float* __restrict__ wo_heads,
     float* __restrict__ out_heads, int batch) {
@@ -424,26 +424,30 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
   // first tile in flight BEFORE the q/k/v reduction below (it does not depend on q)
   if (base < t1) { ATT_LOAD(kA, vA, base) }
 
-  // q / k_new / v_new of this head: reduce the QKV split-K partials + bias (in_proj, modules/activation.py:144)
+  // q / k_new / v_new of this head: reduce the QKV split-K partials + bias (in_proj, modules/activation.py:144).  SK is a
+  // compile-time constant so that all 3 SK + 3 loads are issued together: a runtime loop waits for every slab in turn,
+  // SK + 1 dependent memory round trips at the head of the launch with only the first K/V tile in flight.
   f32x4 q4, k4, v4;
   {
     const int NP = 3 * D_MODEL;
     const float* p = qkv_partial + (long)b * NP + h * D_HEAD + c * 4;
-    q4 = *reinterpret_cast<const f32x4*>(p);
-    k4 = *reinterpret_cast<const f32x4*>(p + D_MODEL);
-    v4 = *reinterpret_cast<const f32x4*>(p + 2 * D_MODEL);
-    for (int ks = 1; ks < splitk; ++ks) {
-      const float* pk = p + (long)ks * MB * NP;
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(pk);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(pk + D_MODEL);
-      const f32x4 a2 = *reinterpret_cast<const f32x4*>(pk + 2 * D_MODEL);
+    f32x4 pq[SK], pk[SK], pv[SK];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { q4[e] += a0[e]; k4[e] += a1[e]; v4[e] += a2[e]; }
+    for (int ks = 0; ks < SK; ++ks) {
+      const float* ps = p + (long)ks * MB * NP;
+      pq[ks] = *reinterpret_cast<const f32x4*>(ps);
+      pk[ks] = *reinterpret_cast<const f32x4*>(ps + D_MODEL);
+      pv[ks] = *reinterpret_cast<const f32x4*>(ps + 2 * D_MODEL);
     }
     const float* bp = qkv_bias + h * D_HEAD + c * 4;
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp);
     const f32x4 b1 = *reinterpret_cast<const f32x4*>(bp + D_MODEL);
     const f32x4 b2 = *reinterpret_cast<const f32x4*>(bp + 2 * D_MODEL);
+    q4 = pq[0]; k4 = pk[0]; v4 = pv[0];
+#pragma unroll
+    for (int ks = 1; ks < SK; ++ks)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { q4[e] += pq[ks][e]; k4[e] += pk[ks][e]; v4[e] += pv[ks][e]; }
 #pragma unroll
     for (int e = 0; e < 4; ++e) { q4[e] = (q4[e] + b0[e]) * 0.125f; k4[e] += b1[e]; v4[e] += b2[e]; }
   }
@@ -589,11 +593,12 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
 void launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias, float* kc, float* vc, int Tmax,
                      const int* slot_meta, float* xp_out, float* part_o, float* part_ml, int nsplit, int batch,
                      const float* wo_heads, float* out_heads, hipStream_t s) {
+  if (splitk != 4) { fprintf(stderr, "launch_dec_attn: the QKV split-K factor is compiled in (4), got %d\n", splitk); abort(); }
   if (wo_heads && nsplit == 1)
-    hipLaunchKernelGGL(dec_attn_kernel<true>, dim3(N_HEAD, (batch + 1) / 2, 1), dim3(ATT_WAVES * 64 * 2), 0, s, qkv_partial,
-                       splitk, qkv_bias, kc, vc, Tmax, slot_meta, xp_out, part_o, part_ml, 1, wo_heads, out_heads, batch);
+    hipLaunchKernelGGL((dec_attn_kernel<true, 4>), dim3(N_HEAD, (batch + 1) / 2, 1), dim3(ATT_WAVES * 64 * 2), 0, s, qkv_partial,
+                       qkv_bias, kc, vc, Tmax, slot_meta, xp_out, part_o, part_ml, 1, wo_heads, out_heads, batch);
   else
-    hipLaunchKernelGGL(dec_attn_kernel<false>, dim3(N_HEAD, batch, nsplit), dim3(ATT_WAVES * 64), 0, s, qkv_partial, splitk,
+    hipLaunchKernelGGL((dec_attn_kernel<false, 4>), dim3(N_HEAD, batch, nsplit), dim3(ATT_WAVES * 64), 0, s, qkv_partial,
                        qkv_bias, kc, vc, Tmax, slot_meta, xp_out, part_o, part_ml, nsplit, nullptr, nullptr, batch);
 }
 
@@ -689,6 +694,7 @@ __device__ __forceinline__ int wave_sum64i_fast(int x) {
 // topk_sampling (models/vallex.py:836-853) + the stop rule (:572-598) + -- when a.emb_tab is set -- the start of the NEXT
 // decode step for the row: embedding of the committed token at its position and norm1 of layer 0 in the packed-x image
 // (what dec_embed_ln_pack does as a separate launch).  One launch + one kernel boundary less per step.
+template <int SK>
 __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
   __shared__ float lg[64 * SPL];
   const int b = blockIdx.x, lane = threadIdx.x;
@@ -698,24 +704,24 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
   const int ngen = a.n_gen[b], pos = a.cur_pos[b], ctx = a.ctx_len[b], tlen = a.text_len[b], slot = a.slot_of[b];
 
   {
-    float t[SPL];
+    // all SPL x SK loads are independent and issued together (SK is a compile-time constant and the tail index is clamped,
+    // not branched around: a conditional load per slab makes the compiler wait for each of the 17 groups in turn)
+    float pp[SPL][SK];
 #pragma unroll
-    for (int i = 0; i < SPL; ++i) {                 // all SPL x splitk loads are independent: issue, then add
-      const int n = lane + 64 * i;
-      t[i] = -INFINITY;
-      if (n < AR_LOGITS) {
-        float p0 = a.partial[(long)b * a.npad + n];
-        float p1 = a.splitk > 1 ? a.partial[((long)1 * MB + b) * a.npad + n] : 0.f;
-        float p2 = a.splitk > 2 ? a.partial[((long)2 * MB + b) * a.npad + n] : 0.f;
-        float p3 = a.splitk > 3 ? a.partial[((long)3 * MB + b) * a.npad + n] : 0.f;
-        t[i] = ((p0 + p1) + p2) + p3;
-      }
+    for (int i = 0; i < SPL; ++i) {
+      const int n = lane + 64 * i, nc = n < AR_LOGITS ? n : AR_LOGITS - 1;
+#pragma unroll
+      for (int ks = 0; ks < SK; ++ks) pp[i][ks] = a.partial[((long)ks * MB + b) * a.npad + nc];
     }
 #pragma unroll
     for (int i = 0; i < SPL; ++i) {
       const int n = lane + 64 * i;
-      lg[n] = t[i];
-      if (a.logits_out && n < AR_LOGITS) a.logits_out[(long)b * AR_LOGITS + n] = t[i];
+      float t = pp[i][0];
+      if (SK == 2) t = t + pp[i][1];
+      if (SK == 4) t = ((t + pp[i][1]) + pp[i][2]) + pp[i][3];
+      if (n >= AR_LOGITS) t = -INFINITY;
+      lg[n] = t;
+      if (a.logits_out && n < AR_LOGITS) a.logits_out[(long)b * AR_LOGITS + n] = t;
     }
   }
   __syncthreads();
@@ -857,7 +863,10 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
 }
 
 void launch_dec_sample(const SampleArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(dec_sample_kernel, dim3(a.batch), dim3(64), 0, s, a);
+  if (a.splitk == 4) hipLaunchKernelGGL(dec_sample_kernel<4>, dim3(a.batch), dim3(64), 0, s, a);
+  else if (a.splitk == 2) hipLaunchKernelGGL(dec_sample_kernel<2>, dim3(a.batch), dim3(64), 0, s, a);
+  else if (a.splitk == 1) hipLaunchKernelGGL(dec_sample_kernel<1>, dim3(a.batch), dim3(64), 0, s, a);
+  else { fprintf(stderr, "launch_dec_sample: split-K factor %d is not compiled in\n", a.splitk); abort(); }
 }
 
 // best_of beams (models/vallex.py:525-527 repeats the prompt N times and prefills N times): the prefill ran ONCE, on row 0;
