@@ -20,15 +20,15 @@ def have_gpu() -> bool:
 
 
 def get_model(num_layers, seed, eos_gain=1.0, vocos=False, debug_taps=False, max_new=320, max_prompt=400, max_text=256,
-              max_batch=32, use_graph=True, attn_gain=1.0):
-    key = (num_layers, seed, eos_gain, vocos, debug_taps, max_new, max_prompt, max_text, max_batch, use_graph, attn_gain)
+              max_batch=32, use_graph=True, attn_gain=1.0, cu_mask=0):
+    key = (num_layers, seed, eos_gain, vocos, debug_taps, max_new, max_prompt, max_text, max_batch, use_graph, attn_gain, cu_mask)
     if key not in _MODELS:
         if len(_MODELS) >= 3:                      # keep device memory bounded across the test session
             _MODELS.pop(next(iter(_MODELS))).__dict__.pop("_engine", None)
         m = VALLE(1024, 16, num_layers, norm_first=True, add_prenet=False, prefix_mode=1, share_embedding=True,
                   nar_scale_factor=1.0, prepend_bos=True, num_quantizers=8, engine_max_new=max_new,
                   engine_max_prompt=max_prompt, engine_max_text=max_text, engine_max_batch=max_batch,
-                  engine_debug_taps=debug_taps, engine_use_graph=use_graph)
+                  engine_debug_taps=debug_taps, engine_use_graph=use_graph, engine_cu_mask=cu_mask)
         m.to("cuda:0").load_state_dict(synth.vallex_state_dict(num_layers, seed, eos_gain, attn_gain), strict=True)
         if vocos:
             m.load_vocos_state_dict(synth.vocos_state_dict(2))

@@ -45,6 +45,55 @@ def test_full_model_batch_properties():
         np.testing.assert_array_equal(a, b)
 
 
+def test_odd_batch_with_rows_ending_at_different_steps():
+    """The fused decode attention runs two launch slots per workgroup: 19 rows leave the last workgroup with ONE row, and rows
+    that stop at different steps (the 16*S cap with S = 3..8, models/vallex.py:577) leave workgroups with one or two finished
+    halves while the others go on.  Every row must equal the same row run alone (context-split path), ids and length."""
+    m = get_model(2, 1, 0.0, max_new=160, max_prompt=96, max_text=32, max_batch=32)      # eos_gain 0: only the cap stops a row
+    rng = np.random.default_rng(5)
+    rows = []
+    for i in range(19):
+        tp, sp, st = int(rng.integers(20, 80)), int(rng.integers(1, 3)), int(rng.integers(2, 7))
+        a, t = synth.synth_prompt(tp, sp, seed=300 + i)
+        rows.append(dict(text=np.concatenate([t[0], synth.synth_text(st, 300 + i)]), prompt=a[0], enroll=sp,
+                         prompt_language="en", text_language=("en", "zh", "ja")[i % 3]))
+    us = synth.uniforms(160, 19, 77)
+    out = m.inference_batch(rows, top_k=10, uniforms=us, sync_every=4)
+    lens = [o.shape[0] for o in out]
+    assert lens == [16 * len(r["text"]) for r in rows] and len(set(lens)) > 3, lens
+    for i in (0, 5, 9, 18):                                         # 18: the row that has a workgroup to itself
+        alone = m.inference_batch([rows[i]], top_k=10, uniforms=us[:, i:i + 1])[0]
+        np.testing.assert_array_equal(alone, out[i])
+
+
+def test_contexts_sharing_the_gpu_on_cu_partitions():
+    """vx_config.cu_mask: two contexts confined to disjoint halves of the CUs, driven from two host threads at the same time
+    (bench.py --contexts 2), give exactly the ids of an unconfined context."""
+    import threading
+    from vallex_amd._capi import cu_partition
+    kw = dict(max_new=64, max_prompt=96, max_text=64, max_batch=32)
+    rows = _rows(32, seed0=1200)
+    us = synth.uniforms(64, 32, 5)
+    want = get_model(2, 1, 0.0, **kw).inference_batch(rows, top_k=10, uniforms=us, force_eos_at=40)
+    masks = cu_partition(2)
+    assert masks[0] & masks[1] == 0 and bin(masks[0] | masks[1]).count("1") == 256
+    halves = [get_model(2, 1, 0.0, cu_mask=mk, **kw) for mk in masks]
+    got = [None, None]
+
+    def run(i):
+        for _ in range(3):
+            got[i] = halves[i].inference_batch(rows, top_k=10, uniforms=us, force_eos_at=40)
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for g in got:
+        for a, b in zip(want, g):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_kv_cache_matches_fresh_prefill_full_model():
     m = get_model(12, 0, 0.0, vocos=True, max_new=128, max_prompt=128, max_text=64, max_batch=32)   # eos_gain 0: EOS never in the top-10
     eng = m.engine
