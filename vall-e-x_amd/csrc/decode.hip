@@ -206,10 +206,24 @@ void launch_skinny16_relu_pack(const float* W16, const float* xp, const float* b
 // ------------------------------------------------------------------------------------------------------------
 // row kernels of the step: one 256-thread block per batch row, thread t owns columns 4t..4t+3 of the 1024.
 // ------------------------------------------------------------------------------------------------------------
+// Sum over the 64 lanes, the same value in every lane, without the LDS crossbar: four DPP steps inside each 16-lane row
+// (every lane of a row ends up with the row total), row_bcast15 / row_bcast31 carry the totals of rows 0-2 up into row 3,
+// lane 63 holds the wave total and is broadcast through an SGPR.  (Six ds_bpermute round trips, ~400 cycles, become ~50;
+// the decode step runs 50 of these reductions back to back on its latency chain.)
 __device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  int x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));   // row_half_mirror
+  x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));   // row_mirror
+  x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false));  // row_bcast15 -> rows 1, 3
+  x = __builtin_bit_cast(int, v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false));  // row_bcast31 -> rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // One 64-lane wave per batch row: lane l owns float4 columns c4 = l + 64 i (i < 4) of the 1024 -- no LDS, no barriers.
