@@ -53,7 +53,7 @@ void launch_pack_weight(const float* W, int N, int K, float* Wp, int Npad, hipSt
 // output: raw split-K partial slab [ks][b][n] (row-major per batch row; consumers: dec_attn, dec_reduce_ln_pack, dec_sample)
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restrict__ Wp, const float* __restrict__ xp,
                                                           float* __restrict__ out, int Npad, int K, int splitk) {
-  __shared__ __attribute__((aligned(16))) float red[3 * 16 * 64];
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   // (no "every row has finished" early exit here: reading that flag -- written by the previous step's sampler -- costs a
   // memory round trip before the first weight load of EVERY launch; steps after the last EOS are bounded by sync_every)
   const int nt = blockIdx.x, ks = blockIdx.y;
@@ -85,24 +85,19 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
   }
 #undef VX_SK_LOAD
 
-  // acc[r] = out[b = lane&31][n = nt*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)]
-  if (wid > 0) {
+  // acc[r] = out[b = lane&31][n = nt*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)].  The four waves' partial sums are combined
+  // in parallel: wave w finishes registers 4w..4w+3 (one 16-byte store per lane), summing the waves in ascending order.
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[((wid - 1) * 16 + r) * 64 + lane] = acc[r];
-  }
+  for (int r = 0; r < 16; ++r) red[((wid * 16 + r) * 64) + lane] = acc[r];
   __syncthreads();
-  if (wid == 0) {
+  f32x4 t;
 #pragma unroll
-    for (int w2 = 0; w2 < 3; ++w2)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] += red[(w2 * 16 + r) * 64 + lane];
-    float* dst = out + ((long)ks * MB + (lane & 31)) * Npad + nt * 32 + 4 * (lane >> 5);
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      f32x4 t = {acc[g4 * 4], acc[g4 * 4 + 1], acc[g4 * 4 + 2], acc[g4 * 4 + 3]};
-      *reinterpret_cast<f32x4*>(dst + g4 * 8) = t;
-    }
+  for (int j = 0; j < 4; ++j) {
+    const float* rp = red + ((wid * 4 + j) * 64) + lane;
+    t[j] = ((rp[0] + rp[16 * 64]) + rp[2 * 16 * 64]) + rp[3 * 16 * 64];
   }
+  float* dst = out + ((long)ks * MB + (lane & 31)) * Npad + nt * 32 + 4 * (lane >> 5);
+  *reinterpret_cast<f32x4*>(dst + wid * 8) = t;
 }
 
 void launch_skinny_gemm(const float* Wp, const float* xp, float* partial, int Npad, int K, int splitk,
@@ -142,7 +137,7 @@ __global__ __launch_bounds__(S16_WAVES * 64) void skinny16_relu_pack_kernel(cons
                                                                             const float* __restrict__ xp,
                                                                             const float* __restrict__ bias,
                                                                             float* __restrict__ xp_out, int K) {
-  __shared__ __attribute__((aligned(16))) float red[(S16_WAVES - 1) * 8 * 64];
+  __shared__ __attribute__((aligned(16))) float red[S16_WAVES * 8 * 64];
   const int nt = blockIdx.x;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int KB = K / 16, per = KB / S16_WAVES;        // K = 1024: 64 k-blocks, 8 per wave
@@ -171,30 +166,29 @@ __global__ __launch_bounds__(S16_WAVES * 64) void skinny16_relu_pack_kernel(cons
     VX_S16_LOAD(i)
   }
 #undef VX_S16_LOAD
-  // acc{h}[r] = out[b = 16h + (lane&15)][n = 16nt + 4(lane>>4) + r]
-  if (wid > 0) {
+  // acc{h}[r] = out[b = 16h + (lane&15)][n = 16nt + 4(lane>>4) + r].  Wave 0 finishes acc0 and wave 1 acc1 (each sums the
+  // eight waves' partials in ascending order, adds the bias, applies ReLU and stores its half of the packed image).
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      red[((wid - 1) * 8 + r) * 64 + lane] = acc0[r];
-      red[((wid - 1) * 8 + 4 + r) * 64 + lane] = acc1[r];
-    }
+  for (int r = 0; r < 4; ++r) {
+    red[(wid * 8 + r) * 64 + lane] = acc0[r];
+    red[(wid * 8 + 4 + r) * 64 + lane] = acc1[r];
   }
   __syncthreads();
-  if (wid == 0) {
+  if (wid < 2) {
+    f32x4 a4;
 #pragma unroll
-    for (int w2 = 0; w2 < S16_WAVES - 1; ++w2)
+    for (int r = 0; r < 4; ++r) {
+      float sum = red[(wid * 4 + r) * 64 + lane];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        acc0[r] += red[(w2 * 8 + r) * 64 + lane];
-        acc1[r] += red[(w2 * 8 + 4 + r) * 64 + lane];
-      }
+      for (int w2 = 1; w2 < S16_WAVES; ++w2) sum += red[(w2 * 8 + wid * 4 + r) * 64 + lane];
+      a4[r] = sum;
+    }
     const f32x4 bi = *reinterpret_cast<const f32x4*>(bias + nt * 16 + 4 * kg);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { acc0[r] = fmaxf(acc0[r] + bi[r], 0.f); acc1[r] = fmaxf(acc1[r] + bi[r], 0.f); }
+    for (int r = 0; r < 4; ++r) a4[r] = fmaxf(a4[r] + bi[r], 0.f);
     // n = 16nt + 4kg + r  ->  linear2's k: kb = 2nt + (kg>>1), hi = kg&1, j = r
     float* o = xp_out + (((long)(2 * nt + (kg >> 1)) * 64) + bl + 32 * (kg & 1)) * 4;
-    *reinterpret_cast<f32x4*>(o) = acc0;
-    *reinterpret_cast<f32x4*>(o + 16 * 4) = acc1;
+    *reinterpret_cast<f32x4*>(o + wid * 16 * 4) = a4;
   }
 }
 
@@ -664,11 +658,17 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
   return x ^ (x >> 31);
 }
 
-__device__ __forceinline__ int wave_min64i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-  return v;
+// 64-lane min / max of ints, the same value in every lane: DPP row steps, row_bcast15 / 31 into row 3, lane 63 broadcast
+// (see wave_sum64; `old` = the lane's own value, so lanes the row masks leave out keep it)
+template <bool MAX>
+__device__ __forceinline__ int wave_minmax64i(int v) {
+#define VX_MM(CTRL, RM) { const int t = __builtin_amdgcn_update_dpp(v, v, CTRL, RM, 0xF, false); v = MAX ? max(v, t) : min(v, t); }
+  VX_MM(0xB1, 0xF) VX_MM(0x4E, 0xF) VX_MM(0x141, 0xF) VX_MM(0x140, 0xF) VX_MM(0x142, 0xA) VX_MM(0x143, 0xC)
+#undef VX_MM
+  return __builtin_amdgcn_readlane(v, 63);
 }
+__device__ __forceinline__ int wave_min64i(int v) { return wave_minmax64i<false>(v); }
+__device__ __forceinline__ int wave_max64i(int v) { return wave_minmax64i<true>(v); }
 
 // One wave per row.  The 1025 logits live in registers, lane l owning the CONTIGUOUS indices [17l, 17l+17) so the
 // inverse-CDF running sum follows index order (sequential inside a lane, Hillis-Steele across lanes: a fixed,
@@ -689,8 +689,11 @@ __device__ __forceinline__ float dpp_max16(float x) {
 }
 __device__ __forceinline__ float wave_max64f(float x) {
   x = dpp_max16(x);
-  x = fmaxf(x, __shfl_xor(x, 16, 64));
-  return fmaxf(x, __shfl_xor(x, 32, 64));
+  int v = __builtin_bit_cast(int, x);
+  x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xF, false)));     // row_bcast15
+  v = __builtin_bit_cast(int, x);
+  x = fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xF, false)));     // row_bcast31
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
 __device__ __forceinline__ int dpp_sum16i(int x) {
   x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);
@@ -701,8 +704,9 @@ __device__ __forceinline__ int dpp_sum16i(int x) {
 }
 __device__ __forceinline__ int wave_sum64i_fast(int x) {
   x = dpp_sum16i(x);
-  x += __shfl_xor(x, 16, 64);
-  return x + __shfl_xor(x, 32, 64);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);     // row_bcast15 -> rows 1, 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);     // row_bcast31 -> rows 2, 3
+  return __builtin_amdgcn_readlane(x, 63);
 }
 
 // topk_sampling (models/vallex.py:836-853) + the stop rule (:572-598) + -- when a.emb_tab is set -- the start of the NEXT
@@ -816,7 +820,7 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
     const float t = __shfl_up(incl, o, 64);
     if (lane >= o) incl += t;
   }
-  const float total = __shfl(incl, 63, 64);
+  const float total = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63));
   const float thresh = u * total;
   float c = incl - loc;
   int cand = 0x7fffffff, lastnz = -1;
@@ -829,9 +833,7 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
     }
   }
   cand = wave_min64i(cand);
-  int last_all = lastnz;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) last_all = max(last_all, __shfl_xor(last_all, o, 64));
+  const int last_all = wave_max64i(lastnz);
   int tok = cand == 0x7fffffff ? last_all : cand;
 
   // log-prob of the pick under the filtered distribution (F.log_softmax, models/vallex.py:851-852), accumulated per
