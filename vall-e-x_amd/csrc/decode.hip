@@ -16,6 +16,8 @@
 //     (non-temporal).  Split-K partial slabs are summed in the consumer's prologue -- no atomics, bit-stable.
 //   * per-row lengths / positions / EOS flags live on the device, so the whole step is a fixed launch sequence
 //     (hipGraph-capturable) and the host only polls `active` every few steps.
+#include <vector>
+
 #include "vx_common.h"
 
 namespace vx {
@@ -50,10 +52,36 @@ void launch_pack_weight(const float* W, int N, int K, float* Wp, int Npad, hipSt
 // skinny GEMM: partial[ks][b][n] = sum_{k in slice ks} x[b][k] * W[n][k]
 // grid = (Npad/32, splitk); 4 waves split the block's K slice and reduce through LDS.
 // ------------------------------------------------------------------------------------------------------------
+#ifdef VX_DEV_PROBES
+// Development timeline (tools/step_timeline.py, dev library only): thread 0 of every workgroup of the decode kernels stores
+// the 100 MHz wall clock at a few points; one shared clock, so the gaps BETWEEN kernels show up as well.
+// vx_stamps[type][workgroup < 512][slot < 8]; types: 0 QKV, 1 linear2, 2 predict, 3 linear1, 4 reduce+LN<16>, 5 <8>, 6 dec_attn, 7 sampler
+__device__ unsigned long long vx_stamps[8 * 512 * 8];
+#define VX_STAMP(TYPE, SLOT)                                                                              \
+  do {                                                                                                    \
+    if (threadIdx.x == 0) {                                                                               \
+      const int bl_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                      \
+      if (bl_ < 512) vx_stamps[((TYPE) * 512 + bl_) * 8 + (SLOT)] = wall_clock64();                         \
+    }                                                                                                     \
+  } while (0)
+void dev_read_stamps(unsigned long long* out) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(vx_stamps), sizeof(unsigned long long) * 8 * 512 * 8);
+}
+void dev_clear_stamps() {
+  static std::vector<unsigned long long> z(8 * 512 * 8, 0ull);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(vx_stamps), z.data(), z.size() * sizeof(unsigned long long));
+}
+#else
+#define VX_STAMP(TYPE, SLOT)
+#endif
+
 // output: raw split-K partial slab [ks][b][n] (row-major per batch row; consumers: dec_attn, dec_reduce_ln_pack, dec_sample)
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restrict__ Wp, const float* __restrict__ xp,
                                                           float* __restrict__ out, int Npad, int K, int splitk) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  const int stype_ = Npad == 3 * D_MODEL ? 0 : (Npad == D_MODEL ? 1 : 2);
+  (void)stype_;
+  VX_STAMP(stype_, 0);
   // (no "every row has finished" early exit here: reading that flag -- written by the previous step's sampler -- costs a
   // memory round trip before the first weight load of EVERY launch; steps after the last EOS are bounded by sync_every)
   const int nt = blockIdx.x, ks = blockIdx.y;
@@ -74,6 +102,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
   _Pragma("unroll") for (int u = 0; u < 8; ++u) x[u] = xq[(long)((I) + u) * 64];                    \
   _Pragma("unroll") for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + (long)((I) + u) * 64);
   VX_SK_LOAD(0)
+  VX_STAMP(stype_, 1);
   for (int i = 0;;) {
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -84,12 +113,14 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
     VX_SK_LOAD(i)
   }
 #undef VX_SK_LOAD
+  VX_STAMP(stype_, 2);
 
   // acc[r] = out[b = lane&31][n = nt*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)].  The four waves' partial sums are combined
   // in parallel: wave w finishes registers 4w..4w+3 (one 16-byte store per lane), summing the waves in ascending order.
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[((wid * 16 + r) * 64) + lane] = acc[r];
   __syncthreads();
+  VX_STAMP(stype_, 3);
   f32x4 t;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -98,6 +129,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
   }
   float* dst = out + ((long)ks * MB + (lane & 31)) * Npad + nt * 32 + 4 * (lane >> 5);
   *reinterpret_cast<f32x4*>(dst + wid * 8) = t;
+  VX_STAMP(stype_, 4);
 }
 
 void launch_skinny_gemm(const float* Wp, const float* xp, float* partial, int Npad, int K, int splitk,
@@ -149,10 +181,14 @@ __global__ __launch_bounds__(S16_WAVES * 64) void skinny16_relu_pack_kernel(cons
 
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   f32x4 w[8], x0[8], x1[8];
+  // requested with the first weights: a load in the epilogue would put one more memory round trip behind the MFMAs
+  const f32x4 bi = *reinterpret_cast<const f32x4*>(bias + nt * 16 + 4 * kg);
 #define VX_S16_LOAD(I)                                                                                                   \
   _Pragma("unroll") for (int u = 0; u < 8; ++u) { x0[u] = xq[(long)((I) + u) * 128]; x1[u] = xq[(long)((I) + u) * 128 + 16]; } \
   _Pragma("unroll") for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + (long)((I) + u) * 64);
+  VX_STAMP(3, 0);
   VX_S16_LOAD(0)
+  VX_STAMP(3, 1);
   for (int i = 0;;) {
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -166,6 +202,7 @@ __global__ __launch_bounds__(S16_WAVES * 64) void skinny16_relu_pack_kernel(cons
     VX_S16_LOAD(i)
   }
 #undef VX_S16_LOAD
+  VX_STAMP(3, 2);
   // acc{h}[r] = out[b = 16h + (lane&15)][n = 16nt + 4(lane>>4) + r].  Wave 0 finishes acc0 and wave 1 acc1 (each sums the
   // eight waves' partials in ascending order, adds the bias, applies ReLU and stores its half of the packed image).
 #pragma unroll
@@ -183,13 +220,13 @@ __global__ __launch_bounds__(S16_WAVES * 64) void skinny16_relu_pack_kernel(cons
       for (int w2 = 1; w2 < S16_WAVES; ++w2) sum += red[(w2 * 8 + wid * 4 + r) * 64 + lane];
       a4[r] = sum;
     }
-    const f32x4 bi = *reinterpret_cast<const f32x4*>(bias + nt * 16 + 4 * kg);
 #pragma unroll
     for (int r = 0; r < 4; ++r) a4[r] = fmaxf(a4[r] + bi[r], 0.f);
     // n = 16nt + 4kg + r  ->  linear2's k: kb = 2nt + (kg>>1), hi = kg&1, j = r
     float* o = xp_out + (((long)(2 * nt + (kg >> 1)) * 64) + bl + 32 * (kg & 1)) * 4;
     *reinterpret_cast<f32x4*>(o + wid * 16 * 4) = a4;
   }
+  VX_STAMP(3, 4);
 }
 
 void launch_skinny16_relu_pack(const float* W16, const float* xp, const float* bias, float* xp_out, int N, int K,
@@ -259,6 +296,7 @@ __global__ __launch_bounds__(256) void dec_reduce_ln_pack_kernel(const float* __
                                                                  float* __restrict__ xp) {
   __shared__ float red[2][4];
   const int b = blockIdx.x, t = threadIdx.x, wid = t >> 6, c = t * 4;
+  VX_STAMP(SK == 16 ? 4 : 5, 0);
   f32x4 p[SK > 0 ? SK : 1];
 #pragma unroll
   for (int ks = 0; ks < SK; ++ks) p[ks] = *reinterpret_cast<const f32x4*>(partial + ((long)ks * MB + b) * npad + c);
@@ -278,6 +316,7 @@ __global__ __launch_bounds__(256) void dec_reduce_ln_pack_kernel(const float* __
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = r[e] + v[e];
   if (h) *reinterpret_cast<f32x4*>(h + (long)b * D_MODEL + c) = v;
+  VX_STAMP(SK == 16 ? 4 : 5, 2);
   // LayerNorm (F.layer_norm, eps 1e-5): mean, then the centred second moment
   float s1 = wave_sum64((v[0] + v[1]) + (v[2] + v[3]));
   if ((t & 63) == 0) red[0][wid] = s1;
@@ -295,6 +334,7 @@ __global__ __launch_bounds__(256) void dec_reduce_ln_pack_kernel(const float* __
   for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * gg[e] + be[e];
   // packed-x image: float4 column c4 = t -> kb = c4 >> 1, hi = c4 & 1
   *reinterpret_cast<f32x4*>(xp + (((long)(t >> 1) * 64) + b + 32 * (t & 1)) * 4) = o;
+  VX_STAMP(SK == 16 ? 4 : 5, 4);
 }
 
 void launch_dec_reduce_ln_pack(const float* partial, int splitk, int npad, const float* bias, const float* resid,
@@ -386,6 +426,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
   // dependent round trips at the head of every launch).  The engine orders the slots so that the long contexts sit in
   // the first half and slot y + ceil(batch/2) holds a short one: unfused, the two share a CU (workgroups are dispatched
   // in block-id order, two per CU); fused, they share a workgroup.  Either way every CU streams about the same KV bytes.
+  VX_STAMP(6, 0);
   const int r = FUSE_OUT ? (int)(threadIdx.x >> 9) : 0;
   const int slot = FUSE_OUT ? (int)blockIdx.y + r * (int)gridDim.y : (int)blockIdx.y;
   const bool valid = slot < batch;
@@ -464,6 +505,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
     *reinterpret_cast<f32x4*>(vc + head_base + (long)npast * D_HEAD + c * 4) = v4;
   }
 
+  VX_STAMP(6, 1);
   float m = NEG_BIG, l = 0.f;
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #define ATT_CONSUME(KK, VV, BASE)                                                                  \
@@ -500,6 +542,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
   }
 #undef ATT_LOAD
 #undef ATT_CONSUME
+  VX_STAMP(6, 2);
   // fused out_proj: the first half of this thread's W_o values (n = tid, d < 32 of the head) is requested now -- it does
   // not depend on the attention result and its L2 latency hides under the group / wave combine below; the second half
   // is requested after the combine, when the streaming registers are free
@@ -566,6 +609,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
       if (c == 0) { part_ml[pi * 2] = mt; part_ml[pi * 2 + 1] = lt; }
     }
   }
+  VX_STAMP(6, 3);
   if (FUSE_OUT) {
 #pragma unroll
     for (int dg = 0; dg < 8; ++dg) wo2[dg] = wh[(8 + dg) * D_MODEL];
@@ -596,6 +640,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
       out_heads[((long)h * MB + br) * D_MODEL + threadIdx.x] = acc[rr];
     }
   }
+  VX_STAMP(6, 4);
 }
 
 void launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias, float* kc, float* vc, int Tmax,
@@ -716,6 +761,7 @@ template <int SK>
 __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
   __shared__ float lg[64 * SPL];
   const int b = blockIdx.x, lane = threadIdx.x;
+  VX_STAMP(7, 0);
   // row state: every scalar the kernel needs, requested up front (independent loads)
   const bool act = a.active[b] != 0;
   if (!act && !a.logits_out) return;
@@ -743,6 +789,7 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
     }
   }
   __syncthreads();
+  VX_STAMP(7, 1);
   if (!act || !a.commit) return;
 
   // the draw and the fixed operands of the fused embedding do not depend on the logits: request them now
@@ -864,6 +911,7 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
       a.slot_meta[4 * slot + 1] = ctx + 1;
     }
   }
+  VX_STAMP(7, 2);
   if (stop || !a.emb_tab) return;
   // start of the next step for this row: h = emb[tok] + alpha * pe[pos + 1]; xp = pack(LN(h))   (dec_embed_ln_pack)
   f32x4 hv[4];
@@ -876,6 +924,7 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
     *reinterpret_cast<f32x4*>(a.emb_h + (long)b * D_MODEL + cc) = hv[i];
   }
   ln_pack_row(hv, b, gg, be, a.emb_xp);
+  VX_STAMP(7, 4);
 }
 
 void launch_dec_sample(const SampleArgs& a, hipStream_t s) {

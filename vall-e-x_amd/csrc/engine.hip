@@ -1837,6 +1837,35 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
     HIPCHK(hipEventRecord(e1, c->stream));
     launches = reps;
     bytes = 3.0 * D_MODEL * D_MODEL * 4.0;
+#ifdef VX_DEV_PROBES
+  } else if (which == 3) {
+    // development timeline (tools/step_timeline.py): `reps` graph replays of a ONE-layer decode step (QKV | attention |
+    // reduce+LN | linear1 | linear2 | reduce+LN | predict | sampler) on the live state; the kernels stamp the wall clock
+    // (decode.hip) and the caller fetches the stamps of the last replay with vx_dev_stamps.
+    vx_sampling sp{};
+    sp.struct_size = sizeof(vx_sampling); sp.top_k = 10; sp.temperature = 1.0f; sp.seed = 1; sp.force_eos_at = -1; sp.best_of = 1;
+    SampleArgs sa = make_sample_args(c, &sp, 1, nullptr);
+    const int nl_keep = c->NL;
+    c->NL = 1;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    ar_step_launches(c, &sa);
+    HIPCHK(hipStreamEndCapture(c->stream, &g));
+    c->NL = nl_keep;
+    HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    for (int w = 0; w < 3; ++w) HIPCHK(hipGraphLaunch(ge, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_clear_stamps();
+    HIPCHK(hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; ++r) HIPCHK(hipGraphLaunch(ge, c->stream));
+    HIPCHK(hipEventRecord(e1, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipGraphExecDestroy(ge);
+    launches = reps;
+    bytes = 0;
+#endif
   } else {
     FAIL(VX_EINVAL, "which must be 0, 1 or 2");
   }
@@ -1850,6 +1879,10 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
   HIPCHK(hipGetLastError());
   return VX_OK;
 }
+
+#ifdef VX_DEV_PROBES
+extern "C" int vx_dev_stamps(unsigned long long* out) { dev_read_stamps(out); return VX_OK; }
+#endif
 
 // Stand-alone GEMM micro-benchmark on scratch buffers (kernel development aid; never on the product path):
 // kernel 0 = gemm_f32, 1 = gemm_bf16x3, 2 = gemm_bf16x3_dma, 6 = gemm_f16x2 (the default of the model path);

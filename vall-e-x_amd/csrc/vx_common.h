@@ -157,6 +157,11 @@ struct SampleArgs {
   float* emb_h; float* emb_xp;
 };
 void launch_dec_sample(const SampleArgs& a, hipStream_t s);
+#ifdef VX_DEV_PROBES
+// development timeline of the decode kernels (decode.hip: vx_stamps[8][512][8], 100 MHz wall-clock ticks)
+void dev_read_stamps(unsigned long long* out);
+void dev_clear_stamps();
+#endif
 // best_of: copy row 0's prefilled K/V (L rows per head, every layer) to rows 1 .. beams-1
 void launch_beam_kv_broadcast(float* kc, float* vc, long cache_layer, int layers, int Tmax, int L, int beams, hipStream_t s);
 void launch_dec_force_token(const int* tok, int* cur_tok, int* cur_pos, int* ctx_len, int* n_gen, int* gen,
