@@ -1882,6 +1882,7 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
 
 #ifdef VX_DEV_PROBES
 extern "C" int vx_dev_stamps(unsigned long long* out) { dev_read_stamps(out); return VX_OK; }
+extern "C" int vx_dev_gemm_stamps(unsigned long long* out) { dev_read_gemm_stamps(out); return VX_OK; }
 #endif
 
 // Stand-alone GEMM micro-benchmark on scratch buffers (kernel development aid; never on the product path):

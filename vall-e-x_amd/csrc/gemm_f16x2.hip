@@ -83,8 +83,25 @@ void launch_split2h(const float* x, int ldx, long rows, int K, const int* gather
                      gather, planes, plane_stride, tile_rows, range_flag);
 }
 
+#ifdef VX_DEV_PROBES
+// development aid (tools/gemm_timeline.py): shader-clock stamps of wave 0 of the first 256 workgroups around two consecutive
+// k-steps in steady state: [0] before the rendezvous, [1] after it, [2] DMA of the next stage issued, [3] fragment reads issued,
+// [4] MFMAs issued, then the same five for the second k-step at [5..9]; [10] loop done, [11] epilogue done, [12] entry
+__device__ unsigned long long vx_gstamps[256 * 16];
+#define VX_GSTAMP(COND, SLOT)                                                                     \
+  do {                                                                                            \
+    if ((COND) && threadIdx.x == 0 && blockIdx.x < 256) vx_gstamps[blockIdx.x * 16 + (SLOT)] = __builtin_readcyclecounter(); \
+  } while (0)
+void dev_read_gemm_stamps(unsigned long long* out) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(vx_gstamps), sizeof(unsigned long long) * 256 * 16);
+}
+#else
+#define VX_GSTAMP(COND, SLOT)
+#endif
+
 // V = 0 product kernel.  Timing probes (VX_DEV_PROBES builds, tools/gemm_bench.py; results meaningless): V = 1 no DMA after the
-// first two tiles; V = 2 no MFMAs; V = 3 fragments read once; V = 4 no barriers / vmcnt waits (racy).
+// first two tiles; V = 2 no MFMAs; V = 3 fragments read once; V = 4 no barriers / vmcnt waits (racy); V = 11 / 12 operands staged
+// through registers instead of LDS-DMA (12: without the MFMAs).
 template <int V>
 __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
   __shared__ __attribute__((aligned(1024))) unsigned char stage0[HSTAGE];
@@ -159,7 +176,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
     // transposed product (A operand = W rows); per (i, jn): tail x head, head x tail into acc_t, head x head into acc_h
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if (V == 2 || V == 9) {
+      if (V == 2 || V == 9 || V == 12) {
 #pragma unroll
         for (int jn = 0; jn < 2; ++jn) {
           acc_t[i][jn][0] += (float)w[1][jn][0] * (float)a[i][0][0] + (float)w[0][jn][1] * (float)a[i][1][1];
@@ -175,15 +192,30 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
       for (int jn = 0; jn < 2; ++jn) acc_t[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][jn], a[i][1], acc_t[i][jn], 0, 0, 0);
     }
   };
+  // probes 11 / 12 (12: without the MFMAs): the same pipeline with the operands staged through REGISTERS (global_load_dwordx4,
+  // then ds_write_b128 one k-step later) instead of LDS-DMA -- same LDS image (lane i of a DMA instruction lands at +16 i)
+  f16x8 rg[HNDMA];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int j = 0; j < HNDMA; ++j) rg[j] = *reinterpret_cast<const f16x8*>(src[j] + kt * kstep[j]);
+  };
+  auto lwrite = [&](unsigned char* stage) {
+#pragma unroll
+    for (int j = 0; j < HNDMA; ++j) *reinterpret_cast<f16x8*>(stage + lds_off[j] + lane * 16) = rg[j];
+  };
   f16x8 w0[2][2], a0[2][2], w1[2][2], a1[2][2];
-  auto ktile = [&](const unsigned char* stage, unsigned char* other, int kt_next, bool more, bool first) {
+  auto ktile = [&](const unsigned char* stage, unsigned char* other, int kt_next, bool more, bool first, int sb) {
+    (void)sb;
     if (more && (V != 1 || kt_next < 2)) dma(other, kt_next);
+    VX_GSTAMP(sb >= 0, sb + 2);
     if (V != 3 || first) {
       frags(stage, 0, w0, a0);
       frags(stage, 1, w1, a1);
     }
+    VX_GSTAMP(sb >= 0, sb + 3);
     mfmas(w0, a0);
     mfmas(w1, a1);
+    VX_GSTAMP(sb >= 0, sb + 4);
   };
   auto rendezvous = [&]() {
     if (V == 4) return;
@@ -192,15 +224,41 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
   };
 
   const int nk = g.K / HK;
+  VX_GSTAMP(true, 12);
+  if (V == 11 || V == 12) {
+    gload(0);
+    lwrite(stage0);
+    if (nk > 1) gload(1);
+    for (int kt = 0; kt < nk; kt += 2) {
+      __syncthreads();
+      if (kt + 1 < nk) { lwrite(stage1); if (kt + 2 < nk) gload(kt + 2); }
+      frags(stage0, 0, w0, a0); frags(stage0, 1, w1, a1);
+      mfmas(w0, a0); mfmas(w1, a1);
+      if (kt + 1 < nk) {
+        __syncthreads();
+        if (kt + 2 < nk) { lwrite(stage0); if (kt + 3 < nk) gload(kt + 3); }
+        frags(stage1, 0, w0, a0); frags(stage1, 1, w1, a1);
+        mfmas(w0, a0); mfmas(w1, a1);
+      }
+    }
+  } else {
   dma(stage0, 0);
   for (int kt = 0; kt < nk; kt += 2) {
+    const bool st = V == 0 && kt == 8;              // dev builds: stamp k-steps 8 and 9
+    (void)st;
+    VX_GSTAMP(st, 0);
     rendezvous();
-    ktile(stage0, stage1, kt + 1, kt + 1 < nk, kt == 0);
+    VX_GSTAMP(st, 1);
+    ktile(stage0, stage1, kt + 1, kt + 1 < nk, kt == 0, st ? 0 : -1);
     if (kt + 1 < nk) {
+      VX_GSTAMP(st, 5);
       rendezvous();
-      ktile(stage1, stage0, kt + 2, kt + 2 < nk, false);
+      VX_GSTAMP(st, 6);
+      ktile(stage1, stage0, kt + 2, kt + 2 < nk, false, st ? 5 : -1);
     }
   }
+  }
+  VX_GSTAMP(true, 10);
   if (V == 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
 
   // epilogue: C = heads + cross / 2048 (+ bias, activation, residual as in the bf16x3 kernels).
@@ -281,6 +339,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
       }
     }
   }
+  VX_GSTAMP(true, 11);
 }
 
 void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s) {
@@ -303,6 +362,8 @@ void launch_gemm_f16x2_probe(const GemmX3Args& g, int variant, hipStream_t s) {
   else if (variant == 8) hipLaunchKernelGGL(gemm_f16x2_kernel<8>, grid, block, 0, s, g);
   else if (variant == 9) hipLaunchKernelGGL(gemm_f16x2_kernel<9>, grid, block, 0, s, g);
   else if (variant == 10) hipLaunchKernelGGL(gemm_f16x2_kernel<10>, grid, block, 0, s, g);
+  else if (variant == 11) hipLaunchKernelGGL(gemm_f16x2_kernel<11>, grid, block, 0, s, g);
+  else if (variant == 12) hipLaunchKernelGGL(gemm_f16x2_kernel<12>, grid, block, 0, s, g);
   else hipLaunchKernelGGL(gemm_f16x2_kernel<4>, grid, block, 0, s, g);
 }
 #endif

@@ -158,6 +158,7 @@ struct SampleArgs {
 };
 void launch_dec_sample(const SampleArgs& a, hipStream_t s);
 #ifdef VX_DEV_PROBES
+void dev_read_gemm_stamps(unsigned long long* out);     // gemm_f16x2.hip: shader-clock stamps around two k-steps, [256][16]
 // development timeline of the decode kernels (decode.hip: vx_stamps[8][512][8], 100 MHz wall-clock ticks)
 void dev_read_stamps(unsigned long long* out);
 void dev_clear_stamps();
