@@ -1,5 +1,6 @@
 """CPU: numerics of the f16x2 arithmetic of the full-sequence projections (vall-e-x_amd/csrc/gemm_f16x2.hip, the default since
-round 2): x = h + t/2048 with h = fp16(x), t = fp16((x - h) * 2048); a.b ~= h.h + (h.t + t.h)/2048.
+round 2): X = x * 2^s, h = fp16(X), t = fp16(X - h) (activations s = 5, every weight tensor its own s from max |w|);
+A.B ~= h.h + h.t + t.h in one fp32 accumulator, descaled by 2^-(sa + sw).
   * its representation error sits well inside the accumulation noise of an ordinary fp32 matmul;
   * with that error injected into every multi-row projection and into both contractions of the full-sequence attention of the
     oracle (prefill + NAR), the greedy / sampled token ids of the live-reference goldens do not change (all eight short goldens
@@ -17,9 +18,19 @@ from oracle import vallex_oracle as VO
 from oracle.make_golden import CASES, GOLD, case_inputs
 
 
-def _split_np(x):
-    h = x.astype(np.float16)
-    t = ((x - h.astype(np.float32)) * 2048).astype(np.float16)
+ACT_SHIFT = 5                                                                # vx_common.h: H2_ACT_SHIFT
+
+
+def _w_shift(w):
+    """engine.hip split_w: max |w| * 2^shift in [16384, 32768)"""
+    mx = float(np.abs(np.asarray(w)).max())
+    return int(np.clip(15 - np.frexp(mx)[1], 0, 24)) if mx > 0 else 24
+
+
+def _split_np(x, shift):
+    X = (x * np.float32(2.0 ** shift)).astype(np.float32)
+    h = X.astype(np.float16)
+    t = (X - h.astype(np.float32)).astype(np.float16)
     return h.astype(np.float64), t.astype(np.float64)
 
 
@@ -29,9 +40,11 @@ def test_representation_error_is_below_fp32_accumulation_noise():
     A = rng.standard_normal((128, K)).astype(np.float32)                     # LayerNorm-like activations
     W = (rng.uniform(-1, 1, (128, K)) / np.sqrt(K)).astype(np.float32)       # weights ~ 1/sqrt(K)
     exact = A.astype(np.float64) @ W.astype(np.float64).T
-    ah, at = _split_np(A)
-    wh, wt = _split_np(W)
-    h2 = ah @ wh.T + (ah @ wt.T + at @ wh.T) / 2048
+    sw = _w_shift(W)
+    ah, at = _split_np(A, ACT_SHIFT)
+    wh, wt = _split_np(W, sw)
+    assert np.abs(ah).max() < 65504 and 16384 <= np.abs(wh).max() <= 32768
+    h2 = (ah @ wh.T + ah @ wt.T + at @ wh.T) * 2.0 ** -(ACT_SHIFT + sw)
     f32 = (A @ W.T).astype(np.float64)
     err_h2, err_f32 = np.abs(h2 - exact), np.abs(f32 - exact)
     assert err_h2.max() < 5e-7 and err_h2.mean() < 1e-7
@@ -77,15 +90,17 @@ def test_token_ids_survive_f16x2_projections(name, monkeypatch):
     monkeypatch.setattr(VO.VallexOracle, "_mha", _mha_h2)                    # attention on f16x2 as well
     orig = VO.F.linear
 
-    def split(x):
-        h = x.to(torch.float16)
-        return h.double(), ((x - h.float()) * 2048).to(torch.float16).double()
+    def split(x, shift):
+        X = x * float(2.0 ** shift)
+        h = X.to(torch.float16)
+        return h.double(), (X - h.float()).to(torch.float16).double()
 
     def linear_h2(inp, w, b=None):
         if inp.dim() >= 2 and inp.shape[0] >= 2 and w.shape[0] >= 256:      # multi-row projections, not the decode steps
-            xh, xt = split(inp.float())
-            wh, wt = split(w.float())
-            y = (xh @ wh.T + (xh @ wt.T + xt @ wh.T) / 2048).float()
+            sw = _w_shift(w.numpy())
+            xh, xt = split(inp.float(), ACT_SHIFT)
+            wh, wt = split(w.float(), sw)
+            y = ((xh @ wh.T + xh @ wt.T + xt @ wh.T) * 2.0 ** -(ACT_SHIFT + sw)).float()
             return y + b if b is not None else y
         return orig(inp, w, b)
 

@@ -436,9 +436,11 @@ __global__ __launch_bounds__(256, 2) void attn_full_x3_kernel(const float* __res
             h2_t h2, t2;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-              const float xv = o[half][g4 * 4 + 2 * pr + k] * inv;
-              h2[k] = (_Float16)xv;
-              t2[k] = (_Float16)((xv - (float)h2[k]) * 2048.0f);
+              _Float16 hk, tk;
+              bool bad = false;                     // |attention output| <= max |v|: the range is checked where V was produced
+              h2_split(o[half][g4 * 4 + 2 * pr + k] * inv, H2_ACT_SCALE, hk, tk, bad);
+              h2[k] = hk;
+              t2[k] = tk;
             }
             hw[g4][pr] = __builtin_bit_cast(unsigned, h2);
             tw[g4][pr] = __builtin_bit_cast(unsigned, t2);

@@ -90,6 +90,7 @@ struct vx_ctx {
   float *kc = nullptr, *vc = nullptr;      // [NL][mbr*16][Tmax][64]
   float *dh = nullptr, *xp = nullptr, *xp_att = nullptr, *xp4 = nullptr;
   float *p_qkv = nullptr, *p_o = nullptr, *p_oh = nullptr, *p_logits = nullptr, *part_o = nullptr, *part_ml = nullptr;
+  std::map<const unsigned short*, int> w_shift;   // f16x2: power-of-two scale exponent of every weight's planes
   bool balance_rows = true;        // dec_attn launch order pairs long with short contexts per CU (VX_BALANCE_ROWS=0: batch order)
   bool fuse_out = true;            // out_proj folded into dec_attn when nsplit == 1 (VX_FUSE_OUT=0: separate skinny GEMM)
   float *d_logits = nullptr, *d_uniforms = nullptr, *sum_logp = nullptr;
@@ -255,7 +256,7 @@ void proj(vx_ctx* c, const float* A, int lda, const float* Wf, const unsigned sh
   }
   const long a_plane = c->gemm_mode == 0 ? h2_plane(M, K, H2_TILE_A) : (long)M * K;
   if (!a_pre) {
-    if (c->gemm_mode == 0) launch_split2h(A, lda, M, K, gather, c->fa3, a_plane, H2_TILE_A, c->range_flag, c->stream);
+    if (c->gemm_mode == 0) launch_split2h(A, lda, M, K, gather, c->fa3, a_plane, H2_TILE_A, c->range_flag, H2_ACT_SCALE, c->stream);
     else launch_split3(A, lda, M, K, gather, c->fa3, a_plane, c->stream);
   }
   GemmX3Args g{};
@@ -263,6 +264,7 @@ void proj(vx_ctx* c, const float* A, int lda, const float* Wf, const unsigned sh
   g.bias = bias; g.resid = resid; g.ldr = ldr;
   g.colscale = nullptr; g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.act = act;
   g.out_planes = out_pl; g.out_plane = out_pl ? h2_plane(M, N, H2_TILE_A) : 0; g.range_flag = c->range_flag;
+  if (c->gemm_mode == 0) g.descale = ldexpf(1.0f, -(H2_ACT_SHIFT + c->w_shift.at(W3)));
   ProfScope ps(c, 2);
   if (c->prof_on) c->prof[2].bytes += 2.0 * (double)M * N * K;
   if (c->gemm_mode == 0) launch_gemm_f16x2(g, c->stream);
@@ -315,8 +317,8 @@ int check_range_flag(vx_ctx* c, const char* where) {
   HIPCHK(hipStreamSynchronize(c->stream));
   if (flag) {
     HIPCHK(hipMemsetAsync(c->range_flag, 0, sizeof(int), c->stream));
-    FAIL(VX_EHIP, "%s: an activation or weight of a projection is outside the fp16 range (|x| >= 65504 or non-finite); "
-                  "rerun with VX_GEMM_X3=1 (bf16x3) or VX_GEMM_F32=1", where);
+    FAIL(VX_EHIP, "%s: an operand of a projection is outside the range of the f16x2 format (|activation| >= 2047, or "
+                  "non-finite); rerun with VX_GEMM_X3=1 (bf16x3) or VX_GEMM_F32=1", where);
   }
   return VX_OK;
 }
@@ -941,10 +943,24 @@ int vx_finalize_weights(vx_ctx* c) {
   if ((e = dev_alloc(c, &c->range_flag, 1))) return e;
   if (c->gemm_mode != 2) {
     const int P = c->gemm_mode == 0 ? 2 : 3;
+    unsigned* d_max = nullptr;
+    if (c->gemm_mode == 0 && (e = dev_alloc(c, reinterpret_cast<int**>(&d_max), 1))) return e;
     auto split_w = [&](const float* Wt, int N, int K, unsigned short** out) -> int {
       if (int e2 = dev_alloc(c, out, (size_t)P * h2_plane(N, K, H2_TILE_W), false)) return e2;
-      if (c->gemm_mode == 0) launch_split2h(Wt, K, N, K, nullptr, *out, h2_plane(N, K, H2_TILE_W), H2_TILE_W, c->range_flag, c->stream);
-      else launch_split3(Wt, K, N, K, nullptr, *out, (long)N * K, c->stream);
+      if (c->gemm_mode == 0) {
+        // f16x2: the tensor's own power-of-two scale, max |w| * 2^shift in [16384, 32768) (vx_common.h); shift in [0, 24]
+        unsigned bits = 0;
+        HIPCHK(hipMemsetAsync(d_max, 0, sizeof(unsigned), c->stream));
+        launch_absmax(Wt, (long)N * K, d_max, c->stream);
+        HIPCHK(hipMemcpyAsync(&bits, d_max, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        float mx;
+        memcpy(&mx, &bits, sizeof mx);
+        int shift = 24;
+        if (mx > 0.f && isfinite(mx)) { int ex; (void)frexpf(mx, &ex); shift = std::max(0, std::min(24, 15 - ex)); }
+        c->w_shift[*out] = shift;
+        launch_split2h(Wt, K, N, K, nullptr, *out, h2_plane(N, K, H2_TILE_W), H2_TILE_W, c->range_flag, ldexpf(1.0f, shift), c->stream);
+      } else launch_split3(Wt, K, N, K, nullptr, *out, (long)N * K, c->stream);
       return VX_OK;
     };
     for (int which = 0; which < 2; ++which)
@@ -1923,8 +1939,8 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
   g0.A = A; g0.lda = K; g0.W = Wt; g0.ldw = K; g0.C = C0; g0.ldc = N; g0.M = M; g0.N = N; g0.K = K; g0.act = ACT_NONE;
   launch_gemm_f32(g0, c->stream);
   if (kernel == 6 || kernel >= 61) {                             // fp16 head / scaled tail planes
-    launch_split2h(A, K, M, K, nullptr, A3, h2_plane(M, K, H2_TILE_A), H2_TILE_A, nullptr, c->stream);
-    launch_split2h(Wt, K, N, K, nullptr, W3, h2_plane(N, K, H2_TILE_W), H2_TILE_W, nullptr, c->stream);
+    launch_split2h(A, K, M, K, nullptr, A3, h2_plane(M, K, H2_TILE_A), H2_TILE_A, nullptr, H2_ACT_SCALE, c->stream);
+    launch_split2h(Wt, K, N, K, nullptr, W3, h2_plane(N, K, H2_TILE_W), H2_TILE_W, nullptr, 16384.0f, c->stream);   // |w| < 1
   } else {
     launch_split3(A, K, M, K, nullptr, A3, (long)M * K, c->stream);
     launch_split3(Wt, K, N, K, nullptr, W3, (long)N * K, c->stream);
@@ -1933,6 +1949,7 @@ int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, in
   const bool h2 = kernel == 6 || kernel >= 61;
   gx.A = A3; gx.a_plane = h2 ? h2_plane(M, K, H2_TILE_A) : (long)M * K; gx.W = W3; gx.w_plane = h2 ? h2_plane(N, K, H2_TILE_W) : (long)N * K; gx.C = C1; gx.ldc = N; gx.M = M; gx.N = N; gx.K = K;
   gx.act = ACT_NONE;
+  gx.descale = ldexpf(1.0f, -(H2_ACT_SHIFT + 14));
   GemmArgs g1 = g0;
   g1.C = C1;
   auto run = [&]() {

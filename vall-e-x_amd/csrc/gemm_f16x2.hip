@@ -1,17 +1,17 @@
 // "f16x2" GEMM -- the default arithmetic of every transformer projection on the full-sequence paths (prefill, NAR).
-// Every fp32 operand is split into an fp16 head and an fp16 tail scaled by 2^11,
-//     x = h + t / 2048,   h = fp16(x),   t = fp16((x - h) * 2048)          (22 significant bits, exact scaling)
-// and   a.b ~= ha.hb + (ha.tb + ta.hb) / 2048      with the two groups in separate fp32 accumulators,
-// i.e. THREE v_mfma_f32_32x32x16_f16 per 32x32x16 block instead of the six bf16 MFMAs of bf16x3 (and 4 instead of 6 operand
+// Every fp32 operand is scaled by a power of two and split into an fp16 head and an fp16 tail AT THE SAME SCALE,
+//     X = x * 2^s,   h = fp16(X),   t = fp16(X - h)          (22 significant bits; s: vx_common.h, H2_ACT_SHIFT / per weight)
+// and   A.B ~= ta.hb + ha.tb + ha.hb      accumulated in ONE fp32 accumulator (smallest terms first), descaled by 2^-(sa + sb)
+// in the epilogue -- THREE v_mfma_f32_32x32x16_f16 per 32x32x16 block instead of the six bf16 MFMAs of bf16x3 (and 4 instead of 6 operand
 // bytes per element); every f16 x f16 product is exact in the fp32 accumulator.  Error per product ~2^-22 relative (the ta.tb
 // term and the tail rounding are dropped): measured on MI355X against the fp32-MFMA kernel on the four NAR shapes (M = 31616,
 // uniform [-1, 1) operands) the max |difference| is 6.5e-5 .. 2.8e-4 -- the SAME as bf16x3's (8.0e-5 .. 4.4e-4): both sit inside
 // the reassociation noise of an fp32 accumulation over K = 1024 .. 4096, which is what separates any two fp32 GEMMs
 // (profiles/r02_gemm_ab.log).  Every live-reference golden (short, sharp-attention, full-length 600 x 8 ids) stays bit-exact.
 // Speed: 270-320 fp32-equivalent TF vs 172-186 for bf16x3 on the same shapes (x 1.6-1.7).
-// fp16 range: |x| must stay below 65504 (LayerNorm outputs, ReLU'd FFN activations, attention outputs and the weights of this
-// model do; the engine checks the weights at load); tails of |x| < 2^-14 fall into fp16 subnormals, which only costs bits that
-// are below 2^-25 absolute.
+// fp16 range: |X| must stay below 65504, i.e. |activation| < 2047 (LayerNorm outputs, ReLU'd FFN activations, attention outputs
+// of this model are far inside; a device flag turns a violation into an error that names the fallbacks); weights are scaled
+// from their own max.  Tails below 2^-14 are fp16 subnormals (honoured by the matrix cores): <= 2^-25 * 2^-s absolute.
 //
 // Structure = gemm_bf16x3_dma.hip: tile 256 x 128 x 32, 8 waves (4 x 2), wave tile 64 x 64, global_load_lds_dwordx4 into two
 // LDS stages (2 planes x (256 + 128) rows x 64 B = 48 KiB each), XOR swizzle applied on the global side.
@@ -29,14 +29,13 @@ constexpr int HM = 256, HN = 128, HK = 32, HLD = 64;
 constexpr int HA_PL = HM * HLD, HW_PL = HN * HLD;                // 16 KiB / 8 KiB
 constexpr int HSTAGE = 2 * HA_PL + 2 * HW_PL;                    // 48 KiB
 constexpr int HNDMA = 6;
-constexpr float TAIL_SCALE = 2048.0f, TAIL_INV = 1.0f / 2048.0f;
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 
 }  // namespace
 
-// x[rows][K] fp32 (row r read at gather ? gather[r] : r) -> planes[p][rows/TR][K/32][TR][32] fp16, p = 0 head, 1 tail * 2048.
+// x[rows][K] fp32 (row r read at gather ? gather[r] : r) -> planes[p][rows/TR][K/32][TR][32] fp16 of X = x * scale, p = 0 head, 1 tail.
 // TILE-major: the TR = 256 (activations) or 128 (weights) rows x K panel that ONE workgroup of the GEMM streams is one
 // contiguous run (TR * K * 2 B per plane), walked linearly by its K loop -- instead of 16 KiB pieces 64 B * rows apart
 // (K-tile-major, the bf16x3 layout), i.e. one DRAM page / TLB entry per K tile and workgroup.  Rows past `rows` in the last
@@ -46,7 +45,7 @@ typedef void __attribute__((address_space(3)))* lptr_t;
 __global__ __launch_bounds__(256) void split2h_kernel(const float* __restrict__ x, int ldx, long rows, int K,
                                                       const int* __restrict__ gather,
                                                       unsigned short* __restrict__ planes, long plane_stride, int tile_rows,
-                                                      int* __restrict__ range_flag) {
+                                                      int* __restrict__ range_flag, float scale) {
   const long total = (long)(K / 32) * rows * 4;
   const int nkt = K / 32;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -62,9 +61,10 @@ __global__ __launch_bounds__(256) void split2h_kernel(const float* __restrict__ 
     bool bad = false;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      bad |= !(fabsf(v[e]) < 65504.0f);
-      h[e] = (_Float16)v[e];                                     // RNE
-      t[e] = (_Float16)((v[e] - (float)h[e]) * TAIL_SCALE);      // exact difference, exact scaling, rounded once
+      _Float16 he, te;
+      h2_split(v[e], scale, he, te, bad);
+      h[e] = he;
+      t[e] = te;
     }
     const long tile = r / tile_rows, rin = r - tile * tile_rows;
     unsigned short* o = planes + ((tile * nkt + kt) * tile_rows + rin) * 32 + ch * 8;
@@ -76,11 +76,23 @@ __global__ __launch_bounds__(256) void split2h_kernel(const float* __restrict__ 
 
 // plane_stride must be >= roundup(rows, tile_rows) * K elements
 void launch_split2h(const float* x, int ldx, long rows, int K, const int* gather, unsigned short* planes, long plane_stride,
-                    int tile_rows, int* range_flag, hipStream_t s) {
+                    int tile_rows, int* range_flag, float scale, hipStream_t s) {
   if (rows <= 0) return;
   const long total = rows * (K / 8);
   hipLaunchKernelGGL(split2h_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, s, x, ldx, rows, K,
-                     gather, planes, plane_stride, tile_rows, range_flag);
+                     gather, planes, plane_stride, tile_rows, range_flag, scale);
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out_bits) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __builtin_bit_cast(unsigned, m));     // non-negative floats order like their bits
+}
+void launch_absmax(const float* x, long n, unsigned* out_bits, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 2048)), dim3(256), 0, s, x, n, out_bits);
 }
 
 #ifdef VX_DEV_PROBES
@@ -150,13 +162,13 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
       __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + kt * kstep[j]), (lptr_t)(stage + lds_off[j]), 16, 0, 0);
   };
 
-  f32x16 acc_h[2][2], acc_t[2][2];                               // heads product | cross terms (scaled by 2048)
+  f32x16 acc[2][2];                                              // ONE accumulator per 32 x 32 block: tail and head products share a scale
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc_h[i][j][r] = 0.f; acc_t[i][j][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int sw = (l31 >> 2) & 3;
   const int a_row = (wm * 64 + l31) * HLD, w_row = (wn * 64 + l31) * HLD;
@@ -173,27 +185,29 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
       for (int p = 0; p < 2; ++p) a[i][p] = *reinterpret_cast<const f16x8*>(stage + p * HA_PL + a_row + i * 32 * HLD + coff);
   };
   auto mfmas = [&](const f16x8 (&w)[2][2], const f16x8 (&a)[2][2]) {
-    // transposed product (A operand = W rows); per (i, jn): tail x head, head x tail into acc_t, head x head into acc_h
+    // transposed product (A operand = W rows); the three terms of a block go into the same accumulator, small ones first; the
+    // four blocks of the wave take turns so that no MFMA waits for the one before it on the same accumulator
+    if (V == 2 || V == 9 || V == 12) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      if (V == 2 || V == 9 || V == 12) {
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn) {
-          acc_t[i][jn][0] += (float)w[1][jn][0] * (float)a[i][0][0] + (float)w[0][jn][1] * (float)a[i][1][1];
-          acc_h[i][jn][0] += (float)w[0][jn][0] * (float)a[i][0][0];
-        }
-        continue;
-      }
-#pragma unroll
-      for (int jn = 0; jn < 2; ++jn) acc_t[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][jn], a[i][0], acc_t[i][jn], 0, 0, 0);
-#pragma unroll
-      for (int jn = 0; jn < 2; ++jn) acc_h[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][jn], a[i][0], acc_h[i][jn], 0, 0, 0);
-#pragma unroll
-      for (int jn = 0; jn < 2; ++jn) acc_t[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][jn], a[i][1], acc_t[i][jn], 0, 0, 0);
+        for (int jn = 0; jn < 2; ++jn)
+          acc[i][jn][0] += (float)w[1][jn][0] * (float)a[i][0][0] + (float)w[0][jn][1] * (float)a[i][1][1] + (float)w[0][jn][0] * (float)a[i][0][0];
+      return;
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][jn], a[i][0], acc[i][jn], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][jn], a[i][1], acc[i][jn], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][jn], a[i][0], acc[i][jn], 0, 0, 0);
   };
-  // probes 11 / 12 (12: without the MFMAs): the same pipeline with the operands staged through REGISTERS (global_load_dwordx4,
-  // then ds_write_b128 one k-step later) instead of LDS-DMA -- same LDS image (lane i of a DMA instruction lands at +16 i)
   f16x8 rg[HNDMA];
   auto gload = [&](int kt) {
 #pragma unroll
@@ -261,7 +275,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
   VX_GSTAMP(true, 10);
   if (V == 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
 
-  // epilogue: C = heads + cross / 2048 (+ bias, activation, residual as in the bf16x3 kernels).
+  // epilogue: C = accumulator * 2^-(sa + sw) (+ bias, activation, residual as in the bf16x3 kernels).
   // With g.out_planes set, the result is NOT written as fp32 rows: it is split on the spot into the f16x2 planes of the NEXT
   // GEMM's A operand (tile-major, K = this N), so linear1 -> linear2 needs neither an fp32 round trip of the [M][4096] hidden
   // activations nor a split pass.  The 32 columns of a (jn) block are exactly one K tile of the consumer; lanes l and l ^ 32 hold
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
         if (n >= g.N) continue;
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaf(acc_t[i][jn][4 * g4 + e], TAIL_INV, acc_h[i][jn][4 * g4 + e]);
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][jn][4 * g4 + e] * g.descale;
         if (g.bias) {
           const f32x4 bi = *reinterpret_cast<const f32x4*>(g.bias + n);
 #pragma unroll
@@ -305,10 +319,10 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
             f16x2v h2, t2;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-              const float x = v[2 * pr + q];
-              bad |= !(fabsf(x) < 65504.0f);
-              h2[q] = (_Float16)x;                               // RNE, as split2h_kernel
-              t2[q] = (_Float16)((x - (float)h2[q]) * TAIL_SCALE);
+              _Float16 hq, tq;
+              h2_split(v[2 * pr + q], H2_ACT_SCALE, hq, tq, bad);   // as split2h_kernel: bit-identical planes
+              h2[q] = hq;
+              t2[q] = tq;
             }
             hw[g4][pr] = __builtin_bit_cast(unsigned, h2);
             tw[g4][pr] = __builtin_bit_cast(unsigned, t2);

@@ -78,10 +78,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int ldx,
           h2_t h2, t2;
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
-            const float xv = o[2 * pr + k];
-            bad |= !(fabsf(xv) < 65504.0f);
-            h2[k] = (_Float16)xv;                                      // RNE, as split2h_kernel
-            t2[k] = (_Float16)((xv - (float)h2[k]) * 2048.0f);
+            _Float16 hk, tk;
+            h2_split(o[2 * pr + k], H2_ACT_SCALE, hk, tk, bad);         // as split2h_kernel: bit-identical planes
+            h2[k] = hk;
+            t2[k] = tk;
           }
           hw[pr] = __builtin_bit_cast(unsigned, h2);
           tw[pr] = __builtin_bit_cast(unsigned, t2);

@@ -53,14 +53,31 @@ struct GemmX3Args {
   // f16x2 only, optional: write the result as the f16x2 A planes of the NEXT GEMM (tile-major, K = this N) instead of fp32 rows
   unsigned short* out_planes; long out_plane;   // plane stride in elements: h2_plane(M, N, H2_TILE_A)
   int* range_flag;
+  float descale;                                // f16x2: 2^-(shift of A + shift of W), applied to the accumulator (exact)
 };
 void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s);                 // 256 x 128 x 32 tile, async LDS fill, any M
 // f16x2 planes are TILE-major: [rows / tile_rows][K/32][tile_rows][32], tile_rows = 256 (A operand) or 128 (W operand);
 // plane_stride >= roundup(rows, tile_rows) * K.  *range_flag = 1 if some |x| does not fit fp16.
 constexpr int H2_TILE_A = 256, H2_TILE_W = 128;
+// f16x2 operand format: X = x * 2^shift,  head = fp16(X),  tail = fp16(X - head)  (both planes at the SAME scale, so all three
+// products of a block go into ONE fp32 accumulator).  Activations use one fixed shift (|x| < 65504 / 32 = 2047: LayerNorm outputs,
+// attention outputs, ReLU'd FFN activations); every weight tensor gets its own from max |w| at load.  A tail below 2^-14 is an
+// fp16 subnormal (v_mfma honours them): absolute error <= 2^-25 * 2^-shift, far below fp32 resolution of the sums.
+constexpr int H2_ACT_SHIFT = 5;
+constexpr float H2_ACT_SCALE = 32.0f;
+#if defined(__HIPCC__)
+__device__ __forceinline__ void h2_split(float x, float scale, _Float16& h, _Float16& t, bool& bad) {
+  const float X = x * scale;                    // power of two: exact
+  bad |= !(fabsf(X) < 65504.0f);
+  h = (_Float16)X;                              // RNE
+  t = (_Float16)(X - (float)h);                 // exact difference, rounded once
+}
+#endif
 inline long h2_plane(long rows, int K, int tile_rows) { return (rows + tile_rows - 1) / tile_rows * tile_rows * (long)K; }
 void launch_split2h(const float* x, int ldx, long rows, int K, const int* gather, unsigned short* planes, long plane_stride,
-                    int tile_rows, int* range_flag, hipStream_t s);
+                    int tile_rows, int* range_flag, float scale, hipStream_t s);
+// max |x| over a tensor, as the bit pattern of the float (device word, atomicMax; zero it first)
+void launch_absmax(const float* x, long n, unsigned* out_bits, hipStream_t s);
 void launch_gemm_bf16x3(const GemmX3Args& g, hipStream_t s);                // register-staged 128 x 128 tile (short row sets)
 void launch_gemm_bf16x3_dma(const GemmX3Args& g, hipStream_t s);            // 256 x 128 tile, async LDS fill (M >= 1024)
 void launch_split3(const float* x, int ldx, long rows, int K, const int* gather, unsigned short* planes,
