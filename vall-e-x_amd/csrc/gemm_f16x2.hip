@@ -114,10 +114,13 @@ void dev_read_gemm_stamps(unsigned long long* out) {
 // V = 0 product kernel.  Timing probes (VX_DEV_PROBES builds, tools/gemm_bench.py; results meaningless): V = 1 no DMA after the
 // first two tiles; V = 2 no MFMAs; V = 3 fragments read once; V = 4 no barriers / vmcnt waits (racy); V = 11 / 12 operands staged
 // through registers instead of LDS-DMA (12: without the MFMAs).
+// V = 13: probe 1 (no DMA) with ONE aliased LDS stage and two workgroups per CU -- does the compute path (fragment reads,
+// MFMAs, barriers) run faster when a second, independent workgroup shares the CU?
 template <int V>
-__global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
+__global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3Args g) {
   __shared__ __attribute__((aligned(1024))) unsigned char stage0[HSTAGE];
-  __shared__ __attribute__((aligned(1024))) unsigned char stage1[HSTAGE];
+  __shared__ __attribute__((aligned(1024))) unsigned char stage1_[V == 13 ? 16 : HSTAGE];
+  unsigned char* const stage1 = V == 13 ? stage0 : stage1_;
 
   constexpr int GM = V == 5 ? 4 : V == 6 ? 16 : V == 7 ? 2 : 8;     // probes 5-7: other XCD-wave shapes (GM x 32/GM tiles)
   const int tiles_m = (g.M + HM - 1) / HM, tiles_n = (g.N + HN - 1) / HN;
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
   f16x8 w0[2][2], a0[2][2], w1[2][2], a1[2][2];
   auto ktile = [&](const unsigned char* stage, unsigned char* other, int kt_next, bool more, bool first, int sb) {
     (void)sb;
-    if (more && (V != 1 || kt_next < 2)) dma(other, kt_next);
+    if (more && ((V != 1 && V != 13) || kt_next < 2)) dma(other, kt_next);
     VX_GSTAMP(sb >= 0, sb + 2);
     if (V != 3 || first) {
       frags(stage, 0, w0, a0);
@@ -378,6 +381,7 @@ void launch_gemm_f16x2_probe(const GemmX3Args& g, int variant, hipStream_t s) {
   else if (variant == 10) hipLaunchKernelGGL(gemm_f16x2_kernel<10>, grid, block, 0, s, g);
   else if (variant == 11) hipLaunchKernelGGL(gemm_f16x2_kernel<11>, grid, block, 0, s, g);
   else if (variant == 12) hipLaunchKernelGGL(gemm_f16x2_kernel<12>, grid, block, 0, s, g);
+  else if (variant == 13) hipLaunchKernelGGL(gemm_f16x2_kernel<13>, grid, block, 0, s, g);
   else hipLaunchKernelGGL(gemm_f16x2_kernel<4>, grid, block, 0, s, g);
 }
 #endif
