@@ -3,7 +3,7 @@ phoneme ids, 600 frames (8.0 s), Ltot = S + Tp + 600 ~ 860-1090, decode contexts
 the LIVE reference (tests/golden/nl12_full_*.npz, made by oracle/make_golden.py FULL_CASES; weights = the bench weights).
 
 Why these exist: with >= 2 such rows in one call the packed row count is >= 1024, so the projections run on
-`gemm_bf16x3_dma_kernel` (engine.hip proj(): M >= 1024) and the NAR attention on `attn_full_x3` at L ~ 983 -- the kernels that
+the large-M GEMM path (engine.hip proj(): `gemm_f16x2`) and the NAR attention (`attn_full_h2`) at L ~ 983 -- the kernels that
 dominate the bench -- and `dec_attn` walks contexts 260 .. 1090.  The short goldens never reach any of that.
 
 Bars: token ids bit-exact (all 8 codebooks, all 600 frames); AR logits (every 50th step, teacher-forced) within 3e-4 abs of
@@ -64,7 +64,7 @@ def test_full_length_row_alone_matches_reference(name):
 @pytest.mark.parametrize("names", [GREEDY, TOPK], ids=["greedy_x3", "topk10_x3"])
 def test_full_length_rows_batched_match_reference(names):
     """three full-length rows (en / zh / ja presets) in ONE inference_batch call: ~2900 packed rows -> DMA bf16x3 GEMM,
-    attn_full_x3 at L ~ 860-1090, ragged dec_attn contexts; each row must still equal its own reference run."""
+    attn_full_h2 at L ~ 860-1090, ragged dec_attn contexts; each row must still equal its own reference run."""
     m = _model()
     rows, cols = [], []
     for n in names:

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libvallex_hip.so")
-SOURCES = ["gemm_f32.hip", "gemm_f16x2.hip", "gemm_bf16x3.hip", "gemm_bf16x3_dma.hip", "rows.hip", "attn_full.hip", "attn_full_x3.hip", "decode.hip", "vocos.hip", "encodec.hip", "engine.hip"]
+SOURCES = ["gemm_f32.hip", "gemm_f16x2.hip", "gemm_bf16x3.hip", "gemm_bf16x3_dma.hip", "rows.hip", "attn_full.hip", "attn_full_x3.hip", "attn_full_h2.hip", "decode.hip", "vocos.hip", "encodec.hip", "engine.hip"]
 HEADERS = ["vx_common.h", os.path.join("..", "..", "include", "vallex_hip.h")]
 # kernarg preload: the first kernel arguments arrive in SGPRs with the wave instead of through an s_load round trip at the
 # head of every launch (the compiler keeps a compatibility prologue for firmware without the feature)

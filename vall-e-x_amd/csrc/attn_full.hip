@@ -173,9 +173,11 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
         float m_tile = MASKED;
 #pragma unroll
         for (int r = 0; r < 16; ++r) m_tile = fmaxf(m_tile, s_cur[r]);
-        const unsigned u = __builtin_bit_cast(unsigned, m_tile);
-        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // VALU op, no LDS round trip
-        m_tile = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+        // inline asm on two distinct registers: the compiler folds the two results of __builtin_amdgcn_permlane32_swap into one
+        // (ROCm 7.2), which left the partner's keys out of the maximum (see attn_full_h2.hip)
+        unsigned ua = __builtin_bit_cast(unsigned, m_tile), ub = ua;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ua), "+v"(ub));   // VALU op, no LDS round trip
+        m_tile = fmaxf(__builtin_bit_cast(float, ua), __builtin_bit_cast(float, ub));
         m_new = fmaxf(m_run, m_tile);                          // finite: key 0 is visible to every query
         alpha = exp_bf(m_run - m_new);
       } else if (i < 13) {                                     // steps 5-12: two exps per step

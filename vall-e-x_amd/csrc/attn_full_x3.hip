@@ -327,9 +327,12 @@ __global__ __launch_bounds__(256, 2) void attn_full_x3_kernel(const float* __res
         for (int r = 0; r < 16; ++r) m_tile = fmaxf(m_tile, s_cur[r]);
         pin(m_tile);
       } else if constexpr (i == 5) {                           // the other 16 keys live in lane ^ 32
-        const unsigned um = __builtin_bit_cast(unsigned, m_tile);
-        const auto sw = __builtin_amdgcn_permlane32_swap(um, um, false, false);
-        m_tile = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+        // the other 16 keys of the query live in lane ^ 32.  Inline asm on two distinct registers: the compiler folds the two
+        // results of __builtin_amdgcn_permlane32_swap into one (ROCm 7.2), which silently left the partner's half out of the
+        // maximum -- still a common, valid stabiliser for the pair, but p could exceed 1 (and overflow an fp16 head)
+        unsigned ua = __builtin_bit_cast(unsigned, m_tile), ub = ua;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ua), "+v"(ub));
+        m_tile = fmaxf(__builtin_bit_cast(float, ua), __builtin_bit_cast(float, ub));
         m_new = fmaxf(m_run, m_tile);                          // finite: key 0 is visible to every query
         alpha = exp_bf(m_run - m_new);
         pin(m_new);

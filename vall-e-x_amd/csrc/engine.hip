@@ -74,7 +74,8 @@ struct vx_ctx {
   // arithmetic of the transformer projections of prefill / NAR: 0 = f16x2 (default; gemm_f16x2.hip), 1 = bf16x3
   // (VX_GEMM_X3=1; gemm_bf16x3*.hip), 2 = exact fp32 MFMA (VX_GEMM_F32=1; gemm_f32.hip).  All three keep every golden's ids.
   int gemm_mode = 0;
-  bool attn_x3 = true;                        // bf16x3 attention (attn_full_x3.hip); VX_ATTN_F32=1 keeps the fp32 MFMA kernel
+  bool attn_x3 = true;                        // 16-bit-plane attention (h2 or x3); VX_ATTN_F32=1 keeps the fp32 MFMA kernel
+  bool attn_h2 = true;                        // f16x2 attention (attn_full_h2.hip); VX_ATTN_X3=1: bf16x3 (attn_full_x3.hip)
   int* range_flag = nullptr;       // device flag: an operand of an f16x2 GEMM did not fit fp16 (checked after every phase)
   unsigned short* fa3b = nullptr;  // second plane buffer: linear1 writes linear2's A planes straight from its epilogue (f16x2 mode)
   unsigned short* fa3 = nullptr;   // activation planes [2 or 3][M][K<=4096]
@@ -289,7 +290,10 @@ int full_layer(vx_ctx* c, const LayerW& L, long M, const int* seq_off, const int
   {
     ProfScope ps(c, 3);
     if (c->prof_on) c->prof[3].bytes += attn_flops;
-    if (c->attn_x3)
+    if (c->attn_x3 && c->attn_h2)
+      launch_attn_full_h2(c->fqkv, att_pl ? nullptr : c->fatt, seq_off, seq_len, prefix_len, batch, max_len, c->stream,
+                          att_pl ? c->fa3 : nullptr, pl1024, c->range_flag);
+    else if (c->attn_x3)
       launch_attn_full_x3(c->fqkv, att_pl ? nullptr : c->fatt, seq_off, seq_len, prefix_len, batch, max_len, 0, c->stream,
                           att_pl ? c->fa3 : nullptr, pl1024);
     else launch_attn_full(c->fqkv, c->fatt, seq_off, seq_len, prefix_len, batch, max_len, c->stream);
@@ -311,14 +315,15 @@ int full_layer(vx_ctx* c, const LayerW& L, long M, const int* seq_off, const int
 
 // f16x2 operands must fit fp16: the split kernels raise a device flag instead of producing inf heads silently
 int check_range_flag(vx_ctx* c, const char* where) {
-  if (c->gemm_mode != 0) return VX_OK;
+  if (c->gemm_mode != 0 && !(c->attn_x3 && c->attn_h2)) return VX_OK;
   int flag = 0;
   HIPCHK(hipMemcpyAsync(&flag, c->range_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (flag) {
     HIPCHK(hipMemsetAsync(c->range_flag, 0, sizeof(int), c->stream));
-    FAIL(VX_EHIP, "%s: an operand of a projection is outside the range of the f16x2 format (|activation| >= 2047, or "
-                  "non-finite); rerun with VX_GEMM_X3=1 (bf16x3) or VX_GEMM_F32=1", where);
+    FAIL(VX_EHIP, "%s: an operand of a projection or of the attention is outside the range of the f16x2 format (|activation|, "
+                  "|q|/8, |k| or |v| >= 2047, or non-finite); rerun with VX_GEMM_X3=1 VX_ATTN_X3=1 (bf16x3) or VX_GEMM_F32=1 "
+                  "VX_ATTN_F32=1", where);
   }
   return VX_OK;
 }
@@ -883,6 +888,7 @@ int vx_finalize_weights(vx_ctx* c) {
   if (const char* ev = getenv("VX_GEMM_X3")) if (ev[0] == '1') c->gemm_mode = 1;
   if (const char* ev = getenv("VX_GEMM_F32")) if (ev[0] == '1') c->gemm_mode = 2;
   if (const char* ev = getenv("VX_ATTN_F32")) c->attn_x3 = !(ev[0] == '1');
+  if (const char* ev = getenv("VX_ATTN_X3")) c->attn_h2 = !(ev[0] == '1');
   if ((e = dev_alloc(c, &c->fxn, (size_t)M * d))) return e;
   if ((e = dev_alloc(c, &c->fqkv, (size_t)M * 3 * d))) return e;
   // in f16x2 mode the attention output and the FFN hidden activations only ever exist as operand planes (fa3 / fa3b)
@@ -2050,6 +2056,7 @@ int vx_bench_attn(vx_ctx* c, int32_t batch, int32_t len, int32_t causal, int32_t
 #else
     else if (variant < 10) return;
 #endif
+    else if (variant == 20) launch_attn_full_h2(qkv, out, meta, meta + batch, pre, batch, len, c->stream, nullptr, 0, nullptr);
     else launch_attn_full_x3(qkv, out, meta, meta + batch, pre, batch, len, variant - 10, c->stream);
   };
   run();
@@ -2067,15 +2074,30 @@ int vx_bench_attn(vx_ctx* c, int32_t batch, int32_t len, int32_t causal, int32_t
   *avg_us = (double)ms * 1e3 / reps;
   if (max_diff) {
     *max_diff = -1.0;
-    if (variant == 0 || variant == 10) {
+    if (variant == 0 || variant == 10 || variant == 20) {
       launch_attn_full(qkv, ref, meta, meta + batch, pre, batch, len, c->stream);
       TRY(hipStreamSynchronize(c->stream));
       std::vector<float> ho((size_t)M * D_MODEL), hr((size_t)M * D_MODEL);
       TRY(hipMemcpy(ho.data(), out, ho.size() * 4, hipMemcpyDeviceToHost));
       TRY(hipMemcpy(hr.data(), ref, hr.size() * 4, hipMemcpyDeviceToHost));
       double md = 0;
+      int shown = 0;
+      if (getenv("VX_ATTN_DEBUG")) {
+        std::map<int, int> per_head, per_row;
+        long nn = 0;
+        for (size_t i = 0; i < ho.size(); ++i)
+          if (ho[i] != ho[i]) { ++nn; per_head[(int)((i % D_MODEL) / D_HEAD)]++; per_row[(int)(i / D_MODEL)]++; }
+        fprintf(stderr, "NaN outputs: %ld of %zu; heads:", nn, ho.size());
+        for (auto& kv : per_head) fprintf(stderr, " %d:%d", kv.first, kv.second);
+        fprintf(stderr, "\nrows (first 40):");
+        int k = 0;
+        for (auto& kv : per_row) if (k++ < 40) fprintf(stderr, " %d:%d", kv.first, kv.second);
+        fprintf(stderr, "\n");
+      }
       for (size_t i = 0; i < ho.size(); ++i) {
         const double d = std::fabs((double)ho[i] - (double)hr[i]);
+        if (getenv("VX_ATTN_DEBUG") && (d != d || d > 1e-3) && shown++ < 12)
+          fprintf(stderr, "attn mismatch at row %zu col %zu: %g vs %g\n", i / D_MODEL, i % D_MODEL, ho[i], hr[i]);
         md = (d > md || d != d) ? (d != d ? 1e30 : d) : md;
       }
       *max_diff = md;

@@ -126,6 +126,10 @@ void launch_attn_full(const float* qkv, float* out, const int* seq_off, const in
 void launch_attn_full_x3(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
                          int batch, int max_len, int variant, hipStream_t s, unsigned short* planes = nullptr,
                          long plane_stride = 0);
+// f16x2 version (attn_full_h2.hip): three f16 MFMAs per block, operands scaled by powers of two (see the file); *range_flag = 1
+// if an operand head did not fit fp16 (the output is then non-finite)
+void launch_attn_full_h2(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
+                         int batch, int max_len, hipStream_t s, unsigned short* planes, long plane_stride, int* range_flag);
 #ifdef VX_DEV_PROBES
 void launch_attn_full_probe(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
                             int batch, int max_len, int variant, hipStream_t s);   // timing probes (tools/attn_bench.py)
