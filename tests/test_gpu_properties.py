@@ -149,14 +149,17 @@ def test_stop_rules_lengths():
 
 @pytest.mark.gpu
 def test_attention_kernels_agree():
-    """bf16x3 attention (product path) against the exact-fp32 MFMA kernel on the same scratch data, ragged tail and
-    prefix-LM mask included: fp32-class agreement (both accumulate in fp32; the x3 split is exact to 2^-27)."""
+    """f16x2 attention (product path, variant 20) and bf16x3 attention (VX_ATTN_X3=1, variant 10) against the exact-fp32 MFMA
+    kernel on the same scratch data, ragged tail and prefix-LM mask included: fp32-class agreement (all accumulate in fp32; the
+    splits are exact to 2^-22 / 2^-27).  A NaN here is how an fp16 head overflow would show (P is scaled by 2^14 relative to the
+    running maximum, which therefore has to be the true maximum of BOTH lanes that share a query)."""
     import vallex_amd
     eng = vallex_amd.Engine(num_layers=1, max_batch=1, max_text=8, max_prompt=8, max_new=8, with_vocos=False)
     for batch, length in ((8, 77), (32, 988)):
         for causal in (False, True):
-            _, diff = eng.bench_attn(batch, length, causal, 10, 1)
-            assert 0.0 <= diff < 5e-6, (batch, length, causal, diff)
+            for variant in (20, 10):
+                _, diff = eng.bench_attn(batch, length, causal, variant, 1)
+                assert 0.0 <= diff < 5e-6, (batch, length, causal, variant, diff)
 
 
 @pytest.mark.gpu

@@ -25,6 +25,7 @@ KERNELS = {  # json suffix -> (kernel-name substring, what the algorithmic bytes
     "skinny_gemm": "skinny_gemm_kernel",
     "skinny16": "skinny16_relu_pack_kernel",
     "attn_full_x3": "attn_full_x3_kernel",
+    "attn_full_h2": "attn_full_h2_kernel",
 }
 
 
