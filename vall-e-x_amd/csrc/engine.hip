@@ -2081,23 +2081,8 @@ int vx_bench_attn(vx_ctx* c, int32_t batch, int32_t len, int32_t causal, int32_t
       TRY(hipMemcpy(ho.data(), out, ho.size() * 4, hipMemcpyDeviceToHost));
       TRY(hipMemcpy(hr.data(), ref, hr.size() * 4, hipMemcpyDeviceToHost));
       double md = 0;
-      int shown = 0;
-      if (getenv("VX_ATTN_DEBUG")) {
-        std::map<int, int> per_head, per_row;
-        long nn = 0;
-        for (size_t i = 0; i < ho.size(); ++i)
-          if (ho[i] != ho[i]) { ++nn; per_head[(int)((i % D_MODEL) / D_HEAD)]++; per_row[(int)(i / D_MODEL)]++; }
-        fprintf(stderr, "NaN outputs: %ld of %zu; heads:", nn, ho.size());
-        for (auto& kv : per_head) fprintf(stderr, " %d:%d", kv.first, kv.second);
-        fprintf(stderr, "\nrows (first 40):");
-        int k = 0;
-        for (auto& kv : per_row) if (k++ < 40) fprintf(stderr, " %d:%d", kv.first, kv.second);
-        fprintf(stderr, "\n");
-      }
       for (size_t i = 0; i < ho.size(); ++i) {
         const double d = std::fabs((double)ho[i] - (double)hr[i]);
-        if (getenv("VX_ATTN_DEBUG") && (d != d || d > 1e-3) && shown++ < 12)
-          fprintf(stderr, "attn mismatch at row %zu col %zu: %g vs %g\n", i / D_MODEL, i % D_MODEL, ho[i], hr[i]);
         md = (d > md || d != d) ? (d != d ? 1e30 : d) : md;
       }
       *max_diff = md;
