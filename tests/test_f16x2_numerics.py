@@ -52,18 +52,21 @@ def test_representation_error_is_below_fp32_accumulation_noise():
 
 
 def _mha_h2(self, x, prefix, mask, past=None):
-    """VallexOracle._mha with both contractions of FULL-SEQUENCE attention (T >= 2: prefill / NAR) on the f16x2 scheme."""
+    """VallexOracle._mha with both contractions of FULL-SEQUENCE attention (T >= 2: prefill / NAR) on the f16x2 scheme of
+    attn_full_h2.hip: Q/8 and K split at 2^5, P at 2^14 (relative to the row maximum), V at 2^5, tails at the heads' scale."""
     import math
     import torch.nn.functional as F
 
-    def split(t):
-        h = t.to(torch.float16)
-        return h.double(), ((t - h.float()) * 2048).to(torch.float16).double()
+    def split(t, shift):
+        X = t.float() * float(2.0 ** shift)
+        h = X.to(torch.float16)
+        assert torch.isfinite(h.float()).all()
+        return h.double(), (X - h.float()).to(torch.float16).double()
 
-    def mm(a, b):                                                        # a @ b with f16x2 operands
-        ah, at = split(a.float())
-        bh, bt = split(b.float())
-        return (ah @ bh + (ah @ bt + at @ bh) / 2048).float()
+    def mm(a, sa, b, sb):                                                # a @ b with f16x2 operands at 2^sa / 2^sb
+        ah, at = split(a, sa)
+        bh, bt = split(b, sb)
+        return ((ah @ bh + ah @ bt + at @ bh) * 2.0 ** -(sa + sb)).float()
 
     T = x.shape[0]
     qkv = F.linear(x, self.w[prefix + ".in_proj_weight"], self.w[prefix + ".in_proj_bias"])
@@ -76,11 +79,15 @@ def _mha_h2(self, x, prefix, mask, past=None):
         k = torch.cat((past[0], k), dim=-2)
         v = torch.cat((past[1], v), dim=-2)
     full = T >= 2
-    att = (mm(q * (1.0 / math.sqrt(hd)), k.transpose(-2, -1)) if full else (q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(hd)))
+    att = (mm(q * (1.0 / math.sqrt(hd)), 5, k.transpose(-2, -1), 5) if full else (q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(hd)))
     if mask is not None:
         att = att.masked_fill(mask, float("-inf"))
-    att = F.softmax(att, dim=-1)
-    y = (mm(att, v) if full else att @ v).transpose(0, 1).contiguous().view(T, self.d)
+    if full:
+        p = torch.exp(att - att.max(dim=-1, keepdim=True).values)       # unnormalised, <= 1: what the kernel splits (x 2^14)
+        y = mm(p, 14, v, 5) / p.sum(dim=-1, keepdim=True)
+    else:
+        y = F.softmax(att, dim=-1) @ v
+    y = y.transpose(0, 1).contiguous().view(T, self.d)
     y = F.linear(y, self.w[prefix + ".out_proj.weight"], self.w[prefix + ".out_proj.bias"])
     return y, (k, v)
 
