@@ -9,9 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vallex_amd  # noqa: E402
 
 eng = vallex_amd.Engine(num_layers=1, max_batch=1, max_text=8, max_prompt=8, max_new=8, with_vocos=False)
-M = 31616
+M = int(os.environ.get("GEMM_M", 31616))
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-kernels = [(0, "f32"), (2, "x3-dma"), (6, "f16x2")]
+kernels = [(0, "f32"), (2, "x3-dma"), (7, "f16x2 256x128"), (8, "f16x2 256x256")]
 for (N, K) in ((3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)):
     res = {k: [] for k, _ in kernels}
     diff = {}

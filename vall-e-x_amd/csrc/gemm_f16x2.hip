@@ -25,10 +25,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int HM = 256, HN = 128, HK = 32, HLD = 64;
-constexpr int HA_PL = HM * HLD, HW_PL = HN * HLD;                // 16 KiB / 8 KiB
-constexpr int HSTAGE = 2 * HA_PL + 2 * HW_PL;                    // 48 KiB
-constexpr int HNDMA = 6;
+constexpr int HM = 256, HK = 32, HLD = 64;                       // TN (columns of a tile) = 128 or 256: template parameter
+constexpr int HA_PL = HM * HLD;                                  // 16 KiB per A plane and stage
+constexpr int WTR = H2_TILE_W;                                   // rows of a W plane tile (256): a TN = 128 tile is half of one
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
@@ -116,8 +115,13 @@ void dev_read_gemm_stamps(unsigned long long* out) {
 // through registers instead of LDS-DMA (12: without the MFMAs).
 // V = 13: probe 1 (no DMA) with ONE aliased LDS stage and two workgroups per CU -- does the compute path (fragment reads,
 // MFMAs, barriers) run faster when a second, independent workgroup shares the CU?
-template <int V>
+// TN = 256: a 256 x 256 tile (wave tile 64 x 128, 128 accumulator registers -- possible since the single accumulator): a third
+// less operand traffic per flop and half the barriers; its fragments are read one k16 step at a time (48 registers).
+template <int V, int TN>
 __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3Args g) {
+  constexpr int HN = TN, HW_PL = TN * HLD, HSTAGE = 2 * HA_PL + 2 * HW_PL;     // 48 / 64 KiB per stage
+  constexpr int HNDMA = HSTAGE / (8 * 1024);                                    // 1 KiB DMA instructions per wave and stage: 6 / 8
+  constexpr int NJ = TN / 64;                                                   // 32-column blocks of a wave: 2 / 4
   __shared__ __attribute__((aligned(1024))) unsigned char stage0[HSTAGE];
   __shared__ __attribute__((aligned(1024))) unsigned char stage1_[V == 13 ? 16 : HSTAGE];
   unsigned char* const stage1 = V == 13 ? stage0 : stage1_;
@@ -140,8 +144,9 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1, hi = lane >> 5, l31 = lane & 31;
 
-  // DMA plan: instruction q = wid * 6 + j of a stage; q < 32: A plane q / 16, rows 16 (q % 16) ..; else W plane (q - 32) / 8,
-  // rows 16 ((q - 32) % 8) ...  Lane -> (row l / 4 of the 16, LDS chunk slot l % 4), swizzle on the global side.
+  // DMA plan: instruction q = wid * HNDMA + j of a stage; q < 32: A plane q / 16, rows 16 (q % 16) ..; else W plane
+  // (q - 32) / (TN / 16), rows 16 ((q - 32) % (TN / 16)) ...  Lane -> (row l / 4 of the 16, LDS chunk slot l % 4), swizzle on the
+  // global side.  W planes are tiled in 256 rows: a TN = 128 tile is the upper or lower half of one.
   const unsigned short* src[HNDMA];
   int lds_off[HNDMA];
   long kstep[HNDMA];
@@ -150,13 +155,13 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
     const int q = wid * HNDMA + j;
     const bool isA = q < 32;
     const int qq = isA ? q : q - 32;
-    const int p = isA ? qq >> 4 : qq >> 3, r16 = isA ? qq & 15 : qq & 7;
-    const int row = r16 * 16 + (lane >> 2);
+    const int p = isA ? qq >> 4 : qq / (TN / 16), r16 = isA ? qq & 15 : qq % (TN / 16);
+    const int row = r16 * 16 + (lane >> 2) + (isA ? 0 : (tn * TN) % WTR);
     const int ch = (lane & 3) ^ ((lane >> 4) & 3);
-    // tile-major planes: this workgroup's A (W) panel is one contiguous run of K/32 blocks of HM (HN) rows x 32
-    const long tile0 = (V == 8 || V == 9) ? 0 : (long)(isA ? tm : tn) * (g.K / HK) * ((isA ? HM : HN) * HK);   // probes 8/9: every workgroup streams tile 0 (all L2 hits)
+    // tile-major planes: a panel is K/32 blocks of 256 rows x 32 (this workgroup's rows of each block are one contiguous run)
+    const long tile0 = (V == 8 || V == 9) ? 0 : (long)(isA ? tm : (tn * TN) / WTR) * (g.K / HK) * ((isA ? HM : WTR) * HK);   // probes 8/9: every workgroup streams tile 0 (all L2 hits)
     src[j] = (isA ? g.A + p * g.a_plane : g.W + p * g.w_plane) + tile0 + (long)row * HK + ch * 8;
-    kstep[j] = (long)(isA ? HM : HN) * HK;
+    kstep[j] = (long)(isA ? HM : WTR) * HK;
     lds_off[j] = (isA ? p * HA_PL : 2 * HA_PL + p * HW_PL) + r16 * 1024;
   }
   auto dma = [&](unsigned char* stage, int kt) {
@@ -165,51 +170,51 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
       __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + kt * kstep[j]), (lptr_t)(stage + lds_off[j]), 16, 0, 0);
   };
 
-  f32x16 acc[2][2];                                              // ONE accumulator per 32 x 32 block: tail and head products share a scale
+  f32x16 acc[2][NJ];                                             // ONE accumulator per 32 x 32 block: tail and head products share a scale
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int sw = (l31 >> 2) & 3;
-  const int a_row = (wm * 64 + l31) * HLD, w_row = (wn * 64 + l31) * HLD;
-  auto frags = [&](const unsigned char* stage, int s, f16x8 (&w)[2][2], f16x8 (&a)[2][2]) {
+  const int a_row = (wm * 64 + l31) * HLD, w_row = (wn * (TN / 2) + l31) * HLD;
+  auto frags = [&](const unsigned char* stage, int s, f16x8 (&w)[2][NJ], f16x8 (&a)[2][2]) {
     const int coff = ((2 * s + hi) ^ sw) * 16;
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
-      for (int jn = 0; jn < 2; ++jn)
+      for (int jn = 0; jn < NJ; ++jn)
         w[p][jn] = *reinterpret_cast<const f16x8*>(stage + 2 * HA_PL + p * HW_PL + w_row + jn * 32 * HLD + coff);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int p = 0; p < 2; ++p) a[i][p] = *reinterpret_cast<const f16x8*>(stage + p * HA_PL + a_row + i * 32 * HLD + coff);
   };
-  auto mfmas = [&](const f16x8 (&w)[2][2], const f16x8 (&a)[2][2]) {
+  auto mfmas = [&](const f16x8 (&w)[2][NJ], const f16x8 (&a)[2][2]) {
     // transposed product (A operand = W rows); the three terms of a block go into the same accumulator, small ones first; the
     // four blocks of the wave take turns so that no MFMA waits for the one before it on the same accumulator
     if (V == 2 || V == 9 || V == 12) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
+        for (int jn = 0; jn < NJ; ++jn)
           acc[i][jn][0] += (float)w[1][jn][0] * (float)a[i][0][0] + (float)w[0][jn][1] * (float)a[i][1][1] + (float)w[0][jn][0] * (float)a[i][0][0];
       return;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][jn], a[i][0], acc[i][jn], 0, 0, 0);
+      for (int jn = 0; jn < NJ; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][jn], a[i][0], acc[i][jn], 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][jn], a[i][1], acc[i][jn], 0, 0, 0);
+      for (int jn = 0; jn < NJ; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][jn], a[i][1], acc[i][jn], 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][jn], a[i][0], acc[i][jn], 0, 0, 0);
+      for (int jn = 0; jn < NJ; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][jn], a[i][0], acc[i][jn], 0, 0, 0);
   };
   f16x8 rg[HNDMA];
   auto gload = [&](int kt) {
@@ -220,18 +225,25 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
 #pragma unroll
     for (int j = 0; j < HNDMA; ++j) *reinterpret_cast<f16x8*>(stage + lds_off[j] + lane * 16) = rg[j];
   };
-  f16x8 w0[2][2], a0[2][2], w1[2][2], a1[2][2];
+  f16x8 w0[2][NJ], a0[2][2], w1[2][TN == 128 ? NJ : 1], a1[2][2];
   auto ktile = [&](const unsigned char* stage, unsigned char* other, int kt_next, bool more, bool first, int sb) {
     (void)sb;
     if (more && ((V != 1 && V != 13) || kt_next < 2)) dma(other, kt_next);
     VX_GSTAMP(sb >= 0, sb + 2);
-    if (V != 3 || first) {
+    if constexpr (TN == 128) {
+      if (V != 3 || first) {
+        frags(stage, 0, w0, a0);
+        frags(stage, 1, w1, a1);
+      }
+      VX_GSTAMP(sb >= 0, sb + 3);
+      mfmas(w0, a0);
+      mfmas(w1, a1);
+    } else {                                        // 48 fragment registers: one k16 step at a time
       frags(stage, 0, w0, a0);
-      frags(stage, 1, w1, a1);
+      mfmas(w0, a0);
+      frags(stage, 1, w0, a0);
+      mfmas(w0, a0);
     }
-    VX_GSTAMP(sb >= 0, sb + 3);
-    mfmas(w0, a0);
-    mfmas(w1, a1);
     VX_GSTAMP(sb >= 0, sb + 4);
   };
   auto rendezvous = [&]() {
@@ -242,7 +254,7 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
 
   const int nk = g.K / HK;
   VX_GSTAMP(true, 12);
-  if (V == 11 || V == 12) {
+  if constexpr ((V == 11 || V == 12) && TN == 128) {
     gload(0);
     lwrite(stage0);
     if (nk > 1) gload(1);
@@ -289,12 +301,12 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
     const int m = m0 + wm * 64 + i * 32 + l31;
     if (m >= g.M) continue;
 #pragma unroll
-    for (int jn = 0; jn < 2; ++jn) {
+    for (int jn = 0; jn < NJ; ++jn) {
       unsigned hw[4][2], tw[4][2];                               // [g4][pair]: packed fp16 heads / scaled tails (planes mode)
       bool bad = false;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        const int n = n0 + wn * 64 + jn * 32 + 8 * g4 + 4 * hi;
+        const int n = n0 + wn * (TN / 2) + jn * 32 + 8 * g4 + 4 * hi;
         if (n >= g.N) continue;
         f32x4 v;
 #pragma unroll
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
       }
       if (g.out_planes) {
         // consumer plane element (m, k = n): ((m / 256) * (N / 32) + n / 32) * 256 * 32 + (m % 256) * 32 + n % 32
-        const long blk = ((long)tm * (g.N / HK) + (n0 + wn * 64 + jn * 32) / HK) * (HM * HK) + (long)(wm * 64 + i * 32 + l31) * HK;
+        const long blk = ((long)tm * (g.N / HK) + (n0 + wn * (TN / 2) + jn * 32) / HK) * (HM * HK) + (long)(wm * 64 + i * 32 + l31) * HK;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {                            // columns 16 j .. 16 j + 15 of the K tile
           // lane hi = 0 keeps its g4 = 2j words and wants the partner's g4 = 2j words; lane hi = 1 keeps g4 = 2j + 1
@@ -359,30 +371,33 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
   VX_GSTAMP(true, 11);
 }
 
-void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s) {
-  const int tiles = ((g.M + HM - 1) / HM) * ((g.N + HN - 1) / HN);
+// tn = 0: 256 x 256 tiles when N is a multiple of 256 (every projection of the model), else 256 x 128; 128 / 256: forced (A/B)
+void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s, int tn) {
+  if (tn == 0) tn = (g.N % 256 == 0) ? 256 : 128;
+  const int tiles = ((g.M + HM - 1) / HM) * ((g.N + tn - 1) / tn);
   if (tiles <= 0) return;
-  hipLaunchKernelGGL(gemm_f16x2_kernel<0>, dim3(tiles), dim3(512), 0, s, g);
+  if (tn == 256) hipLaunchKernelGGL((gemm_f16x2_kernel<0, 256>), dim3(tiles), dim3(512), 0, s, g);
+  else hipLaunchKernelGGL((gemm_f16x2_kernel<0, 128>), dim3(tiles), dim3(512), 0, s, g);
 }
 
 #ifdef VX_DEV_PROBES   // timing probes: tools-only build (vall-e-x_amd/_build.py --dev), never in the product library
 void launch_gemm_f16x2_probe(const GemmX3Args& g, int variant, hipStream_t s) {
-  const int tiles = ((g.M + HM - 1) / HM) * ((g.N + HN - 1) / HN);
+  const int tiles = ((g.M + HM - 1) / HM) * ((g.N + 127) / 128);
   if (tiles <= 0) return;
   const dim3 grid(tiles), block(512);
-  if (variant == 1) hipLaunchKernelGGL(gemm_f16x2_kernel<1>, grid, block, 0, s, g);
-  else if (variant == 2) hipLaunchKernelGGL(gemm_f16x2_kernel<2>, grid, block, 0, s, g);
-  else if (variant == 3) hipLaunchKernelGGL(gemm_f16x2_kernel<3>, grid, block, 0, s, g);
-  else if (variant == 5) hipLaunchKernelGGL(gemm_f16x2_kernel<5>, grid, block, 0, s, g);
-  else if (variant == 6) hipLaunchKernelGGL(gemm_f16x2_kernel<6>, grid, block, 0, s, g);
-  else if (variant == 7) hipLaunchKernelGGL(gemm_f16x2_kernel<7>, grid, block, 0, s, g);
-  else if (variant == 8) hipLaunchKernelGGL(gemm_f16x2_kernel<8>, grid, block, 0, s, g);
-  else if (variant == 9) hipLaunchKernelGGL(gemm_f16x2_kernel<9>, grid, block, 0, s, g);
-  else if (variant == 10) hipLaunchKernelGGL(gemm_f16x2_kernel<10>, grid, block, 0, s, g);
-  else if (variant == 11) hipLaunchKernelGGL(gemm_f16x2_kernel<11>, grid, block, 0, s, g);
-  else if (variant == 12) hipLaunchKernelGGL(gemm_f16x2_kernel<12>, grid, block, 0, s, g);
-  else if (variant == 13) hipLaunchKernelGGL(gemm_f16x2_kernel<13>, grid, block, 0, s, g);
-  else hipLaunchKernelGGL(gemm_f16x2_kernel<4>, grid, block, 0, s, g);
+  if (variant == 1) hipLaunchKernelGGL((gemm_f16x2_kernel<1, 128>), grid, block, 0, s, g);
+  else if (variant == 2) hipLaunchKernelGGL((gemm_f16x2_kernel<2, 128>), grid, block, 0, s, g);
+  else if (variant == 3) hipLaunchKernelGGL((gemm_f16x2_kernel<3, 128>), grid, block, 0, s, g);
+  else if (variant == 5) hipLaunchKernelGGL((gemm_f16x2_kernel<5, 128>), grid, block, 0, s, g);
+  else if (variant == 6) hipLaunchKernelGGL((gemm_f16x2_kernel<6, 128>), grid, block, 0, s, g);
+  else if (variant == 7) hipLaunchKernelGGL((gemm_f16x2_kernel<7, 128>), grid, block, 0, s, g);
+  else if (variant == 8) hipLaunchKernelGGL((gemm_f16x2_kernel<8, 128>), grid, block, 0, s, g);
+  else if (variant == 9) hipLaunchKernelGGL((gemm_f16x2_kernel<9, 128>), grid, block, 0, s, g);
+  else if (variant == 10) hipLaunchKernelGGL((gemm_f16x2_kernel<10, 128>), grid, block, 0, s, g);
+  else if (variant == 11) hipLaunchKernelGGL((gemm_f16x2_kernel<11, 128>), grid, block, 0, s, g);
+  else if (variant == 12) hipLaunchKernelGGL((gemm_f16x2_kernel<12, 128>), grid, block, 0, s, g);
+  else if (variant == 13) hipLaunchKernelGGL((gemm_f16x2_kernel<13, 128>), grid, block, 0, s, g);
+  else hipLaunchKernelGGL((gemm_f16x2_kernel<4, 128>), grid, block, 0, s, g);
 }
 #endif
 

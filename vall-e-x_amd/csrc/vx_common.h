@@ -55,10 +55,10 @@ struct GemmX3Args {
   int* range_flag;
   float descale;                                // f16x2: 2^-(shift of A + shift of W), applied to the accumulator (exact)
 };
-void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s);                 // 256 x 128 x 32 tile, async LDS fill, any M
-// f16x2 planes are TILE-major: [rows / tile_rows][K/32][tile_rows][32], tile_rows = 256 (A operand) or 128 (W operand);
+void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s, int tn = 0);     // 256 x (256 | 128) x 32 tiles, async LDS fill, any M
+// f16x2 planes are TILE-major: [rows / tile_rows][K/32][tile_rows][32], tile_rows = 256 (both operands);
 // plane_stride >= roundup(rows, tile_rows) * K.  *range_flag = 1 if some |x| does not fit fp16.
-constexpr int H2_TILE_A = 256, H2_TILE_W = 128;
+constexpr int H2_TILE_A = 256, H2_TILE_W = 256;
 // f16x2 operand format: X = x * 2^shift,  head = fp16(X),  tail = fp16(X - head)  (both planes at the SAME scale, so all three
 // products of a block go into ONE fp32 accumulator).  Activations use one fixed shift (|x| < 65504 / 32 = 2047: LayerNorm outputs,
 // attention outputs, ReLU'd FFN activations); every weight tensor gets its own from max |w| at load.  A tail below 2^-14 is an
