@@ -371,9 +371,10 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
   VX_GSTAMP(true, 11);
 }
 
-// tn = 0: 256 x 256 tiles when N is a multiple of 256 (every projection of the model), else 256 x 128; 128 / 256: forced (A/B)
+// tn = 0: 256 x 256 tiles when N is a multiple of 256 (every projection of the model) and they still fill the chip at least once
+// (short row sets -- one utterance -- keep the 256 x 128 tile: twice the workgroups, half the time per workgroup); 128 / 256: forced
 void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s, int tn) {
-  if (tn == 0) tn = (g.N % 256 == 0) ? 256 : 128;
+  if (tn == 0) tn = (g.N % 256 == 0 && (long)((g.M + HM - 1) / HM) * (g.N / 256) >= 256) ? 256 : 128;
   const int tiles = ((g.M + HM - 1) / HM) * ((g.N + tn - 1) / tn);
   if (tiles <= 0) return;
   if (tn == 256) hipLaunchKernelGGL((gemm_f16x2_kernel<0, 256>), dim3(tiles), dim3(512), 0, s, g);
