@@ -23,9 +23,14 @@ Pinning status
     state-dict with strict=True, and commits tokens/logits to tests/golden/).
     The reference itself ships no golden vectors or tests for this path
     (SURVEY.md §4), so the live reference IS the pin.
-  * Vocos head: **parity unpinned** -- the `vocos`/`encodec` packages and their
-    weights are absent offline; this file is the only statement of that
-    arithmetic until the package is available.
+  * Vocos head: **parity unpinned to the pip package** -- the `vocos`/`encodec`
+    packages and their weights are absent offline.  Partial pins that do exist
+    (tests/test_vocos_oracle_pieces.py): `VocosOracle.head` == the installed
+    `transformers` port of the package's head code (`Xcodec2ISTFTHead`: Linear ->
+    exp/clip -> polar -> vocos.spectral_ops.ISTFT(padding="same"), every sample,
+    edges included); the backbone and `codes_to_features` == the same weights in
+    torch.nn modules wired as recalled -- the backbone's wiring
+    itself therefore still rests on the recalled structure.
 
 The oracle keeps a real KV cache and only embeds the newest token per step; the
 reference re-embeds all of `y` and rebuilds the mask every step
@@ -320,7 +325,7 @@ class VallexOracle:
 
 
 # ---------------------------------------------------------------------------
-# Vocos head (pip `vocos`) -- parity unpinned, see module doc.
+# Vocos head (pip `vocos`) -- parity unpinned to the package, partial pins in the module doc.
 # ---------------------------------------------------------------------------
 class VocosOracle:
     def __init__(self, state_dict: Dict[str, np.ndarray]):

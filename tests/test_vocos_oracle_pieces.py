@@ -6,7 +6,11 @@ section 2).  What CAN be pinned here is that every piece computes what the torch
     vocos.models.VocosBackbone / vocos.modules.ConvNeXtBlock / AdaLayerNorm (recalled structure, SURVEY.md section A.5);
   * codes_to_features: nn.Embedding + offsets, vocos.pretrained.Vocos.codes_to_features;
   * ISTFT head ("same" padding): torch.istft (center=True) on the interior samples, where the two differ only by the 160-sample
-    shift between trimming (n_fft - hop)/2 = 480 and n_fft/2 = 640.
+    shift between trimming (n_fft - hop)/2 = 480 and n_fft/2 = 640;
+  * ISTFT head, EVERY sample incl. the edges, against a third-party port of the package's own head code: the installed
+    `transformers` ships `Xcodec2ISTFTHead` (models/xcodec2/modeling_xcodec2.py), which its docstring declares to be the
+    "same"-padding ISTFT of vocos/spectral_ops.py (gemelo-ai/vocos@c859e3b) behind the Linear -> exp/clip(1e2) -> polar head;
+    built with Vocos-EnCodec's geometry (dim 384, n_fft 1280, hop 320) and our head weights it IS vocos.heads.ISTFTHead.
 """
 import numpy as np
 import torch
@@ -113,3 +117,27 @@ def test_istft_head_equals_torch_istft_on_interior_samples():
     shift = n_fft // 2 - (n_fft - hop) // 2                             # 160
     lo, hi = n_fft, hop * (T - 1) - n_fft                               # fully overlapped region of both
     np.testing.assert_allclose(got[shift + lo: shift + hi].numpy(), ref[lo:hi].numpy(), atol=2e-5, rtol=1e-5)
+
+
+def test_istft_head_equals_transformers_port_of_the_vocos_head():
+    """the head of the restatement == transformers' port of vocos.heads.ISTFTHead + vocos.spectral_ops.ISTFT(padding="same"),
+    every output sample (edges included), also with magnitudes that hit the exp clip at 1e2"""
+    import types
+    from transformers.models.xcodec2.modeling_xcodec2 import Xcodec2ISTFTHead
+    sd = synth.vocos_state_dict(2)
+    orc = VocosOracle(sd)
+    port = Xcodec2ISTFTHead(types.SimpleNamespace(hidden_size=C, n_fft=synth.VOCOS_NFFT, hop_length=synth.VOCOS_HOP)).eval()
+    with torch.no_grad():
+        port.linear.weight.copy_(orc.w["head.out.weight"])
+        port.linear.bias.copy_(orc.w["head.out.bias"])
+    for T, gain in ((1, 1.0), (2, 1.0), (3, 1.0), (40, 1.0), (600, 1.0), (40, 400.0)):
+        x = gain * torch.randn(2, T, C, generator=torch.Generator().manual_seed(10 + T))
+        with torch.no_grad():
+            ref = port(x)[:, 0]                                          # (B, 320 T)
+            got = orc.head(x)
+        assert got.shape == ref.shape == (2, synth.VOCOS_HOP * T)
+        scale = float(ref.abs().max())
+        if gain > 1:                                                     # the clip is really exercised
+            o = torch.nn.functional.linear(x, orc.w["head.out.weight"], orc.w["head.out.bias"])
+            assert float(o[..., : NB // 2].max()) > np.log(1e2)
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-6 * max(scale, 1.0), rtol=1e-5)
