@@ -145,3 +145,48 @@ def test_npz_prompt_wire_format():
         assert lang == "ja"
     finally:
         G.PRESET_DIRS = monkey
+
+
+class _FakeModel:
+    """records what generate_audio* hand to VALLE.inference; returns `frames` frames of zeros"""
+
+    def __init__(self, frames=3):
+        self.calls, self.frames = [], frames
+
+    def inference(self, x, x_lens, y, enroll_x_lens=0, **kw):
+        self.calls.append(dict(x=np.array(x), y=np.array(y), enroll=enroll_x_lens, **kw))
+        return np.zeros((1, self.frames, 8), np.int64) + len(self.calls)
+
+
+class _FakeVocos:
+    def codes_to_features(self, frames):
+        return np.asarray(frames)
+
+    def decode(self, features, bandwidth_id=None):
+        return np.zeros((1, 320 * features.shape[-1]), np.float32)
+
+
+def test_long_text_detects_language_on_the_whole_text_and_flips_the_reference_coin(monkeypatch):
+    """utils/generation.py:166-167 classifies the WHOLE text once (not sentence by sentence); :264 draws the sliding-window
+    coin with torch.rand(1), so torch.manual_seed reproduces which chunks carry their prompt over"""
+    import torch
+    fm = _FakeModel()
+    seen = []
+    monkeypatch.setattr(G, "model", fm)
+    monkeypatch.setattr(G, "vocos", _FakeVocos())
+    monkeypatch.setattr(G, "rng", None)
+    monkeypatch.setattr(G, "language_detector", lambda t: (seen.append(t), "en")[1])
+    monkeypatch.setattr(G, "sentence_splitter", lambda t: t.split("|"))
+    monkeypatch.setattr(G, "text_tokenizer", lambda t: ([7 + (len(t) % 5)] * 4, ["en"] * 4))
+    text = "first sentence|second one|third"
+    torch.manual_seed(1234)
+    expect = [bool(torch.rand(1) < 0.5) for _ in range(3)]               # the reference's draws, in its order
+    torch.manual_seed(1234)
+    wav = G.generate_audio_from_long_text(text, prompt=None, language="auto", mode="sliding-window", seed=5)
+    assert seen == [text]                                                # one detection, on the whole input
+    assert wav.shape == (3 * 3 * 320,) and len(fm.calls) == 3
+    # chunk k+1 is prompted by chunk k's frames exactly where the coin said "carry" (else back to the original = empty prompt)
+    for k in (1, 2):
+        carried = fm.calls[k]["y"].shape[1] == fm.frames
+        assert carried == expect[k - 1], (k, carried, expect)
+        assert fm.calls[k]["enroll"] == (4 if carried else 0)

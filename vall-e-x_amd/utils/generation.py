@@ -34,7 +34,8 @@ vocos = None
 text_tokenizer: Optional[Callable[[str], Tuple[List[int], List[str]]]] = None   # text -> (phone ids, per-id langs)
 sentence_splitter: Optional[Callable[[str], List[str]]] = None
 language_detector: Optional[Callable[[str], str]] = None
-rng = np.random.default_rng()
+rng = None      # test hook: an object with .random() replaces the sliding-window coin; None = the reference's own draw,
+#                `torch.rand(1) < 0.5` (utils/generation.py:264), which follows torch.manual_seed like the reference does
 
 checkpoints_dir = "./checkpoints/"
 model_checkpoint_name = "vallex-checkpoint.pt"
@@ -119,6 +120,16 @@ def _tokenize(text, lang_token) -> Tuple[np.ndarray, Union[List[str], None]]:
     if len(ids) == 0:
         raise ValueError("Empty text is given")
     return np.asarray(ids, np.int32), list(langs)
+
+
+def _carry_coin() -> bool:
+    """utils/generation.py:264: `if torch.rand(1) < 0.5` -- drawn from torch's global generator, so a script that calls
+    torch.manual_seed flips the same coins as it does with the reference."""
+    if rng is not None:
+        return rng.random() < 0.5
+    if torch is not None:
+        return bool(torch.rand(1) < 0.5)
+    return float(np.random.random()) < 0.5
 
 
 def _detect(text, language):
@@ -228,7 +239,8 @@ def generate_audio_from_long_text(text, prompt=None, language="auto", accent="no
         sentences = sentence_splitter(text)
     else:
         sentences = list(text)
-    language = _detect(sentences[0] if sentences else "", language) if language == "auto" else language
+    if language == "auto":                                             # :166-167: langid.classify(text) on the WHOLE input
+        language = _detect(text if isinstance(text, str) else (sentences[0] if sentences else ""), language)
     if prompt is not None:
         audio_prompts, text_prompts, lang_pr = _load_prompt(prompt)
     else:
@@ -246,7 +258,7 @@ def generate_audio_from_long_text(text, prompt=None, language="auto", accent="no
         f = frames.numpy() if torch is not None and isinstance(frames, torch.Tensor) else np.asarray(frames)
         chunks.append(f)
         if mode == "sliding-window":
-            if rng.random() < 0.5:                                     # torch.rand(1) < 0.5  (:264)
+            if _carry_coin():                                          # torch.rand(1) < 0.5  (:264)
                 # encoded_frames[:, :, -NUM_QUANTIZERS:] slices the codebook axis, i.e. keeps ALL frames (:265)
                 audio_prompts = f[:, :, -NUM_QUANTIZERS:].astype(np.int32)
                 text_prompts = np.asarray(phone_tokens, np.int32)[None]             # text_tokens[:, enroll_x_lens:] (:266)
