@@ -72,6 +72,14 @@ SHARP_CASES = {
                              top_k=10, force_eos_at=40, useed=555),
 }
 
+# EOS as the very FIRST sample.  models/vallex.py:579-582 raises SyntaxError("well trained model shouldn't reach here.") only if
+# prompts.shape[1] == y.shape[1]; with prepend_bos=True (utils/generation.py:76) y carries the extra BOS, the condition is never
+# true, and the live reference returns an EMPTY (1, 0, 8) tensor -- pinned here so that the mirror does not "fix" it.
+EDGE_CASES = {
+    "nl2_eos_first": dict(num_layers=2, seed=0, eos_gain=2.5, preset="librispeech_1", n_text=12, lang="en", top_k=1,
+                          force_eos_at=0, useed=None),
+}
+
 # BASELINE C1/C2/C3 shape at FULL length: 12 layers, preset prompt + 100 phoneme ids, EOS forced at
 # 600 frames (8.0 s) => Ltot = S + Tp + 600 ~ 983 for librispeech_1.  Weights = the bench weights (seed 0, eos_gain 0: the EOS
 # logit is exactly 0, never the arg-max and never inside the top-10, so no run ends early).  All six share ONE weight set so
@@ -279,7 +287,7 @@ def main(only=None):
         out = run_reference_continual(c)
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
         print(name, out["codes"].shape, out["codes"][0, :4, 1], flush=True)
-    for name, c in list(CASES.items()) + list(SHARP_CASES.items()) + list(FULL_CASES.items()):
+    for name, c in list(CASES.items()) + list(SHARP_CASES.items()) + list(EDGE_CASES.items()) + list(FULL_CASES.items()):
         if only and name not in only:
             continue
         if c.get("full") and not only and os.path.exists(os.path.join(GOLD, name + ".npz")):

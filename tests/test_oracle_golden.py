@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import synth
-from oracle.make_golden import (CASES, CONTINUAL_CASES, FULL_CASES, FULL_LOGIT_EVERY, GOLD, PRESET_SHAPES, SHARP_CASES,
+from oracle.make_golden import (CASES, CONTINUAL_CASES, EDGE_CASES, FULL_CASES, FULL_LOGIT_EVERY, GOLD, PRESET_SHAPES, SHARP_CASES,
                                 case_inputs, continual_inputs, preset_shape_case)
 from oracle.vallex_oracle import VallexOracle
 
@@ -128,3 +128,19 @@ def test_oracle_matches_reference_on_preset_shapes():
                               force_eos_at=c["force_eos_at"], taps=taps)
         np.testing.assert_array_equal(codes[0], g["codes"][i].astype(np.int64), err_msg=PRESET_SHAPES[i][0])
         np.testing.assert_allclose(taps["ar_logits"][0].numpy(), g["ar_logits0"][i], atol=2e-4, rtol=0)
+
+
+def test_eos_as_first_sample_returns_an_empty_result_like_the_live_reference():
+    """models/vallex.py:579-582 would raise SyntaxError("well trained model shouldn't reach here.") if the stop rule fired with
+    `prompts.shape[1] == y.shape[1]` -- never true with prepend_bos=True (y carries the BOS): the LIVE reference returns an
+    empty (1, 0, 8) tensor (golden nl2_eos_first), and so do the oracle and the mirror (GPU: test_edge_cases_... (b))."""
+    c = EDGE_CASES["nl2_eos_first"]
+    g = np.load(os.path.join(GOLD, "nl2_eos_first.npz"))
+    assert g["codes"].shape == (1, 0, 8) and g["nar_logits0"].shape[0] == 0
+    orc = VallexOracle(synth.vallex_state_dict(c["num_layers"], c["seed"], c["eos_gain"]), c["num_layers"])
+    a, t, text, pl, langs = case_inputs(c)
+    taps = {}
+    codes = orc.inference(text, np.array([text.shape[-1]]), a, t.shape[-1], top_k=1, prompt_language=pl, text_language=langs,
+                          force_eos_at=0, taps=taps)
+    assert codes.shape == (1, 0, 8)
+    np.testing.assert_allclose(taps["ar_logits"][0].numpy(), g["ar_logits"][0], atol=2e-4, rtol=0)
