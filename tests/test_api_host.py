@@ -9,7 +9,7 @@ import pytest
 import vallex_amd
 from oracle import synth
 from oracle.vallex_oracle import sine_pe
-from vallex_amd.models.vallex import VALLE, expected_keys, sine_pe_table
+from vallex_amd.models.vallex import VALLE, expected_keys, sine_pe_table, vocos_expected_keys
 from vallex_amd.utils import generation as G
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -190,3 +190,20 @@ def test_long_text_detects_language_on_the_whole_text_and_flips_the_reference_co
         carried = fm.calls[k]["y"].shape[1] == fm.frames
         assert carried == expect[k - 1], (k, carried, expect)
         assert fm.calls[k]["enroll"] == (4 if carried else 0)
+
+
+def test_vocos_state_dict_keeps_only_the_head_tensors():
+    """the published vocos checkpoint also holds the whole EnCodec model and the ISTFT window: ignored; a missing head tensor
+    fails at load time, not at the first decode"""
+    sd = synth.vocos_state_dict(2)
+    assert list(sd) == vocos_expected_keys()                              # the synthetic dict IS the expected layout
+    extra = dict(sd)
+    extra["feature_extractor.encodec.decoder.model.0.conv.conv.weight_v"] = np.zeros((4, 4, 7), np.float32)
+    extra["feature_extractor.encodec.quantizer.vq.layers.0._codebook.inited"] = np.ones(1, bool)
+    extra["head.istft.window"] = np.hanning(1280).astype(np.float32)
+    m = _valle(2).load_vocos_state_dict(extra)
+    assert list(m._vocos_sd) == vocos_expected_keys() and all(v.dtype == np.float32 for v in m._vocos_sd.values())
+    bad = dict(sd)
+    bad.pop("head.out.bias")
+    with pytest.raises(RuntimeError, match="missing"):
+        _valle(2).load_vocos_state_dict(bad)

@@ -43,6 +43,17 @@ def fresh_seed() -> int:
     return int(np.random.default_rng().integers(0, 2 ** 62))
 
 
+def vocos_expected_keys() -> List[str]:
+    """The tensors of `charactr/vocos-encodec-24khz` the Vocos head computes with: codebook table, embed conv,
+    AdaLayerNorm tables, 8 ConvNeXt blocks, final LayerNorm, ISTFT head projection."""
+    k = ["feature_extractor.codebook_weights", "backbone.embed.weight", "backbone.embed.bias", "backbone.norm.scale.weight",
+         "backbone.norm.shift.weight"]
+    for i in range(8):
+        k += [f"backbone.convnext.{i}." + s for s in ("dwconv.weight", "dwconv.bias", "norm.scale.weight", "norm.shift.weight",
+                                                      "pwconv1.weight", "pwconv1.bias", "pwconv2.weight", "pwconv2.bias", "gamma")]
+    return k + ["backbone.final_layer_norm.weight", "backbone.final_layer_norm.bias", "head.out.weight", "head.out.bias"]
+
+
 def expected_keys(num_layers: int) -> List[str]:
     """State-dict layout of the reference (models/vallex.py:55-264,405-445)."""
     k = ["ar_text_embedding.word_embeddings.weight", "nar_text_embedding.word_embeddings.weight",
@@ -142,8 +153,14 @@ class VALLE:
         return self
 
     def load_vocos_state_dict(self, state_dict):
-        """Weights of `Vocos.from_pretrained('charactr/vocos-encodec-24khz')` (utils/generation.py:89), vocos key names."""
-        self._vocos_sd = {k: _np(v, np.float32) for k, v in state_dict.items()}
+        """Weights of `Vocos.from_pretrained('charactr/vocos-encodec-24khz')` (utils/generation.py:89), vocos key names.  The
+        published checkpoint also carries the whole EnCodec model under `feature_extractor.encodec.*` and the ISTFT window
+        buffer; only the tensors the head computes with (`vocos_expected_keys`) are uploaded, the rest is ignored."""
+        want = vocos_expected_keys()
+        missing = [k for k in want if k not in state_dict]
+        if missing:
+            raise RuntimeError(f"Error(s) in loading the Vocos state_dict: missing {missing[:4]}{'...' if len(missing) > 4 else ''}")
+        self._vocos_sd = {k: _np(state_dict[k], np.float32) for k in want}
         self._engine = None
         return self
 
