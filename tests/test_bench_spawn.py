@@ -11,8 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _json_line(out):
-    lines = [l for l in out.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out
+    # the contract: stdout is EXACTLY one line, the JSON (gloo's "[Gloo] Rank 0 is connected ..." and any other native
+    # chatter on fd 1 must have been routed to stderr)
+    lines = out.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), out
     return json.loads(lines[0])
 
 
