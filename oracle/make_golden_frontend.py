@@ -1,0 +1,97 @@
+"""Golden vectors for the text front-end glue (vall-e-x_amd/utils/g2p.py) from the LIVE reference tokenizer.
+
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden_frontend        (build container only: needs /root/reference)
+
+The reference's `utils.g2p.PhonemeBpeTokenizer` is imported as it is; only its three language modules (`utils/g2p/english.py`,
+`mandarin.py`, `japanese.py`: G2P rules over third-party packages that are not installed) are replaced by stand-in text -> IPA
+converters -- `stand_in_converters()` below, the same functions the test gives to the mirror.  What is pinned is everything
+around them: tag segmentation, conversion order, trailing punctuation, per-character language labels, " " -> "_", BPE ids.
+Writes tests/golden/g2p_frontend.json (cases) and copies the reference's 69-symbol tokenizer file (a data file, like the presets)
+to tests/golden/bpe_69.json.
+"""
+from __future__ import annotations
+
+import json
+import os
+import shutil
+import sys
+import types
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+_EN = {"hello": "həloʊ", "world": "wɜːld", "ok": "oʊkeɪ", "yes": "jɛs"}
+_ZH = {"你好": "ni↓↑xɑʊ↓↑", "世界": "ʂɹ`↓tɕiɛ↓", "好": "xɑʊ↓↑"}
+_JA = {"こんにちは": "koɴnitɕiwa", "はい": "hai"}
+
+
+def _table_converter(table, fallback):
+    def conv(s: str) -> str:
+        out = []
+        for w in s.replace("，", ",").split(" "):
+            core = w.strip(",.!?")
+            tail = w[len(core):] if core and w.startswith(core) else ""
+            out.append(table.get(core, fallback(core)) + tail if core else w)
+        return " ".join(out)
+    return conv
+
+
+def stand_in_converters():
+    """deterministic stand-ins for english_to_ipa2 / chinese_to_ipa / japanese_to_ipa2: a few dictionary words in the symbol
+    set of bpe_69.json, everything else spelled through (unknown characters become [UNK] ids, like in the reference)"""
+    return {"en": _table_converter(_EN, lambda w: w.lower()), "zh": _table_converter(_ZH, lambda w: w),
+            "ja": _table_converter(_JA, lambda w: w)}
+
+
+CASES = [
+    "_[EN]hello world[EN]",
+    "[EN]Hello, world![EN]",
+    "_[ZH]你好 世界[ZH]",
+    "_[JA]こんにちは[JA]",
+    "_[EN]yes[EN][ZH]你好[ZH][JA]はい[JA]",                    # code switching: three segments, three labels
+    "[ZH]好[ZH] text outside any tag is dropped [EN]ok[EN]",
+    "[EN]ok...[EN]",                                            # already ends in punctuation: no full stop added
+    "[EN]hello [ZH]你好[ZH] world[EN]",                          # nested tags: the reference's quirk is part of the contract
+    "[EN]  [EN]",                                               # white space only
+    "no tags at all",                                           # -> empty -> ValueError("Empty text is given")
+]
+
+
+def main():
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    conv = stand_in_converters()
+
+    def module(name, fns):
+        m = types.ModuleType(name)
+        for f, c in fns.items():
+            setattr(m, f, c)
+        sys.modules[name] = m
+
+    unused = lambda s: (_ for _ in ()).throw(AssertionError("not on the cje_cleaners path"))       # noqa: E731
+    module("utils.g2p.english", {"english_to_ipa2": conv["en"], "english_to_lazy_ipa": unused, "english_to_lazy_ipa2": unused})
+    module("utils.g2p.mandarin", {"chinese_to_ipa": conv["zh"], **{f: unused for f in (
+        "number_to_chinese", "chinese_to_bopomofo", "latin_to_bopomofo", "chinese_to_romaji", "chinese_to_lazy_ipa", "chinese_to_ipa2")}})
+    module("utils.g2p.japanese", {"japanese_to_ipa2": conv["ja"], **{f: unused for f in (
+        "japanese_to_romaji_with_accent", "japanese_to_ipa", "japanese_to_ipa3")}})
+    import utils.g2p as G                                         # the reference's own tokenizer class
+    src = os.path.join(REF, "utils", "g2p", "bpe_69.json")
+    tk = G.PhonemeBpeTokenizer(src)
+    out = []
+    for text in CASES:
+        try:
+            ids, langs = tk.tokenize(text.strip())
+            out.append(dict(text=text, ids=[int(i) for i in ids], langs=list(langs)))
+        except ValueError as e:
+            out.append(dict(text=text, error=type(e).__name__, message=str(e)))
+        print(out[-1], flush=True)
+    os.makedirs(GOLD, exist_ok=True)
+    with open(os.path.join(GOLD, "g2p_frontend.json"), "w", encoding="utf-8") as f:
+        json.dump(out, f, ensure_ascii=False, indent=1)
+    shutil.copyfile(src, os.path.join(GOLD, "bpe_69.json"))
+    os.chmod(os.path.join(GOLD, "bpe_69.json"), 0o644)
+
+
+if __name__ == "__main__":
+    main()
