@@ -46,3 +46,33 @@ def test_plugs_into_generation_hook_and_frontend_service(tok):
     assert [t.language for t in out] == ["en", "zh"]
     assert list(out[0].ids) == CASES[0]["ids"] and out[0].langs == CASES[0]["langs"]
     assert set(out[1].langs) == {"zh"}
+
+
+def test_mix_language_code_switching_reaches_the_model_as_per_id_languages(tok, monkeypatch):
+    """README.md:217-222 of the reference: language='mix' with user-written tags -> lang_token '' (macros.py:8-13), prompt
+    language 'en' when there is no prompt (utils/generation.py:123), text_language = the tokenizer's per-id list (:146)."""
+    import numpy as np
+    from vallex_amd.utils import generation as G
+    seen = {}
+
+    class FakeModel:
+        def inference(self, x, x_lens, y, enroll_x_lens=0, **kw):
+            seen.update(x=np.array(x), enroll=enroll_x_lens, **kw)
+            return np.zeros((1, 2, 8), np.int64)
+
+    class FakeVocos:
+        def codes_to_features(self, frames):
+            return np.asarray(frames)
+
+        def decode(self, features, bandwidth_id=None):
+            return np.zeros((1, 320 * features.shape[-1]), np.float32)
+
+    monkeypatch.setattr(G, "model", FakeModel())
+    monkeypatch.setattr(G, "vocos", FakeVocos())
+    monkeypatch.setattr(G, "text_tokenizer", tok.tokenize)
+    wav = G.generate_audio("[ZH]你好[ZH][EN]yes[EN]", language="mix", seed=3)
+    assert wav.shape == (640,)
+    ids, langs = tok.tokenize("[ZH]你好[ZH][EN]yes[EN]")
+    assert list(seen["x"][0]) == list(ids) and seen["enroll"] == 0
+    assert seen["prompt_language"] == "en" and seen["text_language"] == langs and set(langs) == {"zh", "en"}
+    assert seen["top_k"] == -100 and seen["temperature"] == 1                      # utils/generation.py:141-142

@@ -175,7 +175,8 @@ def generate_audio(text, prompt=None, language="auto", accent="no-accent", **kw)
         lang_pr = None
     logging.info(f"synthesize text: {text}")
     encoded_frames, _ = _infer_one(text, audio_prompts, text_prompts, lang_pr, language, accent, **kw)
-    frames = encoded_frames.permute(2, 0, 1) if torch is not None else np.transpose(encoded_frames, (2, 0, 1))  # :148
+    frames = (encoded_frames.permute(2, 0, 1) if torch is not None and isinstance(encoded_frames, torch.Tensor)
+              else np.transpose(np.asarray(encoded_frames), (2, 0, 1)))                                         # :148
     features = vocos.codes_to_features(frames)
     samples = vocos.decode(features, bandwidth_id=np.array([2]))
     s = samples.squeeze()
