@@ -115,6 +115,10 @@ void dev_read_gemm_stamps(unsigned long long* out) {
 // through registers instead of LDS-DMA (12: without the MFMAs).
 // V = 13: probe 1 (no DMA) with ONE aliased LDS stage and two workgroups per CU -- does the compute path (fragment reads,
 // MFMAs, barriers) run faster when a second, independent workgroup shares the CU?
+// V = 14 (TN = 256 only; a real kernel: same sums as V = 0): the eight LDS-DMA instructions of the next stage are not issued back
+// to back right behind the rendezvous -- by all eight waves of the CU at once, with the matrix pipe idle meanwhile -- but one at
+// a time after every sixth MFMA of this K tile (ISA of V = 0: barrier | 8 x [2 v_lshl_add_u64, s_mov m0, global_load_lds] | 6 ds_read |
+// 8 MFMA | 6 ds_read | 16 MFMA | 6 ds_read | 8 MFMA | 6 ds_read | 16 MFMA).
 // TN = 256: a 256 x 256 tile (wave tile 64 x 128, 128 accumulator registers -- possible since the single accumulator): a third
 // less operand traffic per flop and half the barriers; its fragments are read one k16 step at a time (48 registers).
 template <int V, int TN>
@@ -226,9 +230,33 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
     for (int j = 0; j < HNDMA; ++j) *reinterpret_cast<f16x8*>(stage + lds_off[j] + lane * 16) = rg[j];
   };
   f16x8 w0[2][NJ], a0[2][2], w1[2][TN == 128 ? NJ : 1], a1[2][2];
+  // probe 14: one k16 step (fragments + its 24 MFMAs) with DMA instruction 4 s + 0..3 of the next stage behind MFMAs 3, 9, 15, 21
+  auto kstep_spread = [&](const unsigned char* stage, unsigned char* other, int kt_next, bool more, int s, f16x8 (&w)[2][NJ],
+                          f16x8 (&a)[2][2]) {
+    frags(stage, s, w, a);
+    int n = 0;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const int wp = p == 0 ? 1 : 0, ap = p == 1 ? 1 : 0;          // tail.head, head.tail, head.head: the order of mfmas()
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NJ; ++jn) {
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[wp][jn], a[i][ap], acc[i][jn], 0, 0, 0);
+          ++n;
+          if (n % 6 == 3) {
+            const int j = (4 * s + n / 6) % HNDMA;
+            __builtin_amdgcn_sched_barrier(0);
+            if (more)
+              __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + kt_next * kstep[j]), (lptr_t)(other + lds_off[j]), 16, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+    }
+  };
   auto ktile = [&](const unsigned char* stage, unsigned char* other, int kt_next, bool more, bool first, int sb) {
     (void)sb;
-    if (more && ((V != 1 && V != 13) || kt_next < 2)) dma(other, kt_next);
+    if (V != 14 && more && ((V != 1 && V != 13) || kt_next < 2)) dma(other, kt_next);
     VX_GSTAMP(sb >= 0, sb + 2);
     if constexpr (TN == 128) {
       if (V != 3 || first) {
@@ -238,6 +266,9 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
       VX_GSTAMP(sb >= 0, sb + 3);
       mfmas(w0, a0);
       mfmas(w1, a1);
+    } else if constexpr (V == 14) {
+      kstep_spread(stage, other, kt_next, more, 0, w0, a0);
+      kstep_spread(stage, other, kt_next, more, 1, w0, a0);
     } else {                                        // 48 fragment registers: one k16 step at a time
       frags(stage, 0, w0, a0);
       mfmas(w0, a0);
@@ -398,6 +429,9 @@ void launch_gemm_f16x2_probe(const GemmX3Args& g, int variant, hipStream_t s) {
   else if (variant == 11) hipLaunchKernelGGL((gemm_f16x2_kernel<11, 128>), grid, block, 0, s, g);
   else if (variant == 12) hipLaunchKernelGGL((gemm_f16x2_kernel<12, 128>), grid, block, 0, s, g);
   else if (variant == 13) hipLaunchKernelGGL((gemm_f16x2_kernel<13, 128>), grid, block, 0, s, g);
+  else if (variant == 14) {                                      // a 256 x 256 tile kernel: its own grid; N must be a multiple of 256
+    if (g.N % 256 == 0) hipLaunchKernelGGL((gemm_f16x2_kernel<14, 256>), dim3(((g.M + HM - 1) / HM) * (g.N / 256)), block, 0, s, g);
+  }
   else hipLaunchKernelGGL((gemm_f16x2_kernel<4, 128>), grid, block, 0, s, g);
 }
 #endif
