@@ -115,10 +115,12 @@ void dev_read_gemm_stamps(unsigned long long* out) {
 // through registers instead of LDS-DMA (12: without the MFMAs).
 // V = 13: probe 1 (no DMA) with ONE aliased LDS stage and two workgroups per CU -- does the compute path (fragment reads,
 // MFMAs, barriers) run faster when a second, independent workgroup shares the CU?
-// V = 14 (TN = 256 only; a real kernel: same sums as V = 0): the eight LDS-DMA instructions of the next stage are not issued back
-// to back right behind the rendezvous -- by all eight waves of the CU at once, with the matrix pipe idle meanwhile -- but one at
-// a time after every sixth MFMA of this K tile (ISA of V = 0: barrier | 8 x [2 v_lshl_add_u64, s_mov m0, global_load_lds] | 6 ds_read |
-// 8 MFMA | 6 ds_read | 16 MFMA | 6 ds_read | 8 MFMA | 6 ds_read | 16 MFMA).
+// V = 14 / 15 (TN = 256 only; real kernels: same sums as V = 0): the eight LDS-DMA instructions of the next stage are not issued
+// back to back right behind the rendezvous -- by all eight waves of the CU at once, with the matrix pipe idle meanwhile -- but one
+// at a time between the MFMAs of this K tile (ISA of V = 0: barrier | 8 x [2 v_lshl_add_u64, s_mov m0, global_load_lds] | 6 ds_read |
+// 8 MFMA | 6 ds_read | 16 MFMA | 6 ds_read | 8 MFMA | 6 ds_read | 16 MFMA).  14: behind each of the FIRST eight MFMAs (the
+// data still has almost the whole K tile to land: with two stages the landing time is what the next rendezvous waits for);
+// 15: behind every sixth MFMA (even spread; the last requests are issued late).
 // TN = 256: a 256 x 256 tile (wave tile 64 x 128, 128 accumulator registers -- possible since the single accumulator): a third
 // less operand traffic per flop and half the barriers; its fragments are read one k16 step at a time (48 registers).
 template <int V, int TN>
@@ -230,7 +232,8 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
     for (int j = 0; j < HNDMA; ++j) *reinterpret_cast<f16x8*>(stage + lds_off[j] + lane * 16) = rg[j];
   };
   f16x8 w0[2][NJ], a0[2][2], w1[2][TN == 128 ? NJ : 1], a1[2][2];
-  // probe 14: one k16 step (fragments + its 24 MFMAs) with DMA instruction 4 s + 0..3 of the next stage behind MFMAs 3, 9, 15, 21
+  // probes 14 / 15: one k16 step (fragments + its 24 MFMAs) with the next stage's DMA instructions threaded between the MFMAs:
+  // 14: instruction j behind MFMA j + 1 of step 0 (j = 0..7); 15: instruction 4 s + 0..3 behind MFMAs 3, 9, 15, 21 of step s
   auto kstep_spread = [&](const unsigned char* stage, unsigned char* other, int kt_next, bool more, int s, f16x8 (&w)[2][NJ],
                           f16x8 (&a)[2][2]) {
     frags(stage, s, w, a);
@@ -244,8 +247,8 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
         for (int jn = 0; jn < NJ; ++jn) {
           acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[wp][jn], a[i][ap], acc[i][jn], 0, 0, 0);
           ++n;
-          if (n % 6 == 3) {
-            const int j = (4 * s + n / 6) % HNDMA;
+          if (V == 14 ? (s == 0 && n <= HNDMA) : (n % 6 == 3)) {
+            const int j = V == 14 ? n - 1 : (4 * s + n / 6) % HNDMA;
             __builtin_amdgcn_sched_barrier(0);
             if (more)
               __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + kt_next * kstep[j]), (lptr_t)(other + lds_off[j]), 16, 0, 0);
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
   };
   auto ktile = [&](const unsigned char* stage, unsigned char* other, int kt_next, bool more, bool first, int sb) {
     (void)sb;
-    if (V != 14 && more && ((V != 1 && V != 13) || kt_next < 2)) dma(other, kt_next);
+    if (V != 14 && V != 15 && more && ((V != 1 && V != 13) || kt_next < 2)) dma(other, kt_next);
     VX_GSTAMP(sb >= 0, sb + 2);
     if constexpr (TN == 128) {
       if (V != 3 || first) {
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
       VX_GSTAMP(sb >= 0, sb + 3);
       mfmas(w0, a0);
       mfmas(w1, a1);
-    } else if constexpr (V == 14) {
+    } else if constexpr (V == 14 || V == 15) {
       kstep_spread(stage, other, kt_next, more, 0, w0, a0);
       kstep_spread(stage, other, kt_next, more, 1, w0, a0);
     } else {                                        // 48 fragment registers: one k16 step at a time
@@ -429,8 +432,11 @@ void launch_gemm_f16x2_probe(const GemmX3Args& g, int variant, hipStream_t s) {
   else if (variant == 11) hipLaunchKernelGGL((gemm_f16x2_kernel<11, 128>), grid, block, 0, s, g);
   else if (variant == 12) hipLaunchKernelGGL((gemm_f16x2_kernel<12, 128>), grid, block, 0, s, g);
   else if (variant == 13) hipLaunchKernelGGL((gemm_f16x2_kernel<13, 128>), grid, block, 0, s, g);
-  else if (variant == 14) {                                      // a 256 x 256 tile kernel: its own grid; N must be a multiple of 256
-    if (g.N % 256 == 0) hipLaunchKernelGGL((gemm_f16x2_kernel<14, 256>), dim3(((g.M + HM - 1) / HM) * (g.N / 256)), block, 0, s, g);
+  else if (variant == 14 || variant == 15) {                     // 256 x 256 tile kernels: their own grid; N must be a multiple of 256
+    const dim3 grid256(((g.M + HM - 1) / HM) * (g.N / 256));
+    if (g.N % 256 != 0) return;
+    if (variant == 14) hipLaunchKernelGGL((gemm_f16x2_kernel<14, 256>), grid256, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_f16x2_kernel<15, 256>), grid256, block, 0, s, g);
   }
   else hipLaunchKernelGGL((gemm_f16x2_kernel<4, 128>), grid, block, 0, s, g);
 }
