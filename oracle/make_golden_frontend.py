@@ -6,14 +6,14 @@ The reference's `utils.g2p.PhonemeBpeTokenizer` is imported as it is; only its t
 `mandarin.py`, `japanese.py`: G2P rules over third-party packages that are not installed) are replaced by stand-in text -> IPA
 converters -- `stand_in_converters()` below, the same functions the test gives to the mirror.  What is pinned is everything
 around them: tag segmentation, conversion order, trailing punctuation, per-character language labels, " " -> "_", BPE ids.
-Writes tests/golden/g2p_frontend.json (cases) and copies the reference's 69-symbol tokenizer file (a data file, like the presets)
-to tests/golden/bpe_69.json.
+Writes tests/golden/g2p_frontend.json: the cases, plus the symbol table of the reference's `bpe_69.json` (70 entries in id order: five
+special tokens and 65 phoneme characters -- a constant table) from which `build_char_tokenizer` re-creates an equivalent tokenizer
+file with the `tokenizers` library, so that no reference file has to be copied into the repository.
 """
 from __future__ import annotations
 
 import json
 import os
-import shutil
 import sys
 import types
 
@@ -58,6 +58,17 @@ CASES = [
 ]
 
 
+def build_char_tokenizer(symbols, path):
+    """A tokenizer file equivalent to the reference's bpe_69.json: character-level BPE (vocabulary = `symbols` in id order, no
+    merges), `[UNK]` for anything else, Whitespace pre-tokenizer, the first five symbols registered as special tokens."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    tk = Tokenizer(models.BPE(vocab={sym: i for i, sym in enumerate(symbols)}, merges=[], unk_token="[UNK]"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    tk.add_special_tokens(list(symbols[:5]))
+    tk.save(path)
+    return path
+
+
 def main():
     sys.path.insert(0, REF)
     sys.dont_write_bytecode = True
@@ -86,11 +97,20 @@ def main():
         except ValueError as e:
             out.append(dict(text=text, error=type(e).__name__, message=str(e)))
         print(out[-1], flush=True)
+    vocab = json.load(open(src, encoding="utf-8"))["model"]["vocab"]
+    symbols = [sym for sym, _ in sorted(vocab.items(), key=lambda kv: kv[1])]
+    assert [vocab[sym] for sym in symbols] == list(range(len(symbols)))
+    # the re-created tokenizer must encode like the reference's file on every case and on every symbol
+    import tempfile
+    from tokenizers import Tokenizer
+    with tempfile.TemporaryDirectory() as d:
+        mine, ref = Tokenizer.from_file(build_char_tokenizer(symbols, os.path.join(d, "t.json"))), Tokenizer.from_file(src)
+        probe = "".join(symbols[5:]) + " _xyz_" + "".join(symbols[5:][::-1])
+        for text in [probe] + [c["text"] for c in out]:
+            assert mine.encode(text).ids == ref.encode(text).ids, text
     os.makedirs(GOLD, exist_ok=True)
     with open(os.path.join(GOLD, "g2p_frontend.json"), "w", encoding="utf-8") as f:
-        json.dump(out, f, ensure_ascii=False, indent=1)
-    shutil.copyfile(src, os.path.join(GOLD, "bpe_69.json"))
-    os.chmod(os.path.join(GOLD, "bpe_69.json"), 0o644)
+        json.dump(dict(symbols=symbols, cases=out), f, ensure_ascii=False, indent=1)
 
 
 if __name__ == "__main__":

@@ -7,16 +7,20 @@ import os
 import pytest
 
 import vallex_amd  # noqa: F401
-from oracle.make_golden_frontend import stand_in_converters
+from oracle.make_golden_frontend import build_char_tokenizer, stand_in_converters
 from vallex_amd.utils.g2p import PhonemeBpeTokenizer, clean_tagged_text, tagged_segments
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-CASES = json.load(open(os.path.join(GOLD, "g2p_frontend.json"), encoding="utf-8"))
+_G = json.load(open(os.path.join(GOLD, "g2p_frontend.json"), encoding="utf-8"))
+CASES, SYMBOLS = _G["cases"], _G["symbols"]
 
 
 @pytest.fixture(scope="module")
-def tok():
-    return PhonemeBpeTokenizer(os.path.join(GOLD, "bpe_69.json"), stand_in_converters())
+def tok(tmp_path_factory):
+    # an equivalent of the reference's utils/g2p/bpe_69.json, re-created from its symbol table (checked against the reference's
+    # own file by the generator)
+    path = build_char_tokenizer(SYMBOLS, str(tmp_path_factory.mktemp("bpe") / "bpe_69.json"))
+    return PhonemeBpeTokenizer(path, stand_in_converters())
 
 
 @pytest.mark.parametrize("case", CASES, ids=[str(i) for i in range(len(CASES))])
