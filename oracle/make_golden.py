@@ -78,6 +78,12 @@ SHARP_CASES = {
 EDGE_CASES = {
     "nl2_eos_first": dict(num_layers=2, seed=0, eos_gain=2.5, preset="librispeech_1", n_text=12, lang="en", top_k=1,
                           force_eos_at=0, useed=None),
+    # no audio prompt and no prompt text at all (utils/generation.py:121-123: zeros([1, 0, 8]), enroll_x_lens = 0)
+    "nl2_no_prompt": dict(num_layers=2, seed=0, eos_gain=2.5, synth_prompt=(0, 0), prompt_lang="en", n_text=11, lang="en", top_k=1,
+                          force_eos_at=9, useed=None),
+    # the smallest input: one prompt frame, one prompt text id, one text id
+    "nl2_minimal": dict(num_layers=2, seed=3, eos_gain=1.0, synth_prompt=(1, 1), prompt_lang="ja", n_text=1, lang="zh", top_k=1,
+                        force_eos_at=5, useed=None),
 }
 
 # BASELINE C1/C2/C3 shape at FULL length: 12 layers, preset prompt + 100 phoneme ids, EOS forced at

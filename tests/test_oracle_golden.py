@@ -144,3 +144,21 @@ def test_eos_as_first_sample_returns_an_empty_result_like_the_live_reference():
                           force_eos_at=0, taps=taps)
     assert codes.shape == (1, 0, 8)
     np.testing.assert_allclose(taps["ar_logits"][0].numpy(), g["ar_logits"][0], atol=2e-4, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["nl2_no_prompt", "nl2_minimal"])
+def test_oracle_matches_reference_on_smallest_inputs(name):
+    """no audio prompt / prompt text at all (utils/generation.py:121-123) and the smallest possible input (one prompt frame, one
+    prompt id, one text id): oracle ids == the live reference's, first AR logits and NAR stage-0 logits within fp32 distance"""
+    c = EDGE_CASES[name]
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    orc = VallexOracle(synth.vallex_state_dict(c["num_layers"], c["seed"], c["eos_gain"]), c["num_layers"])
+    a, t, text, pl, langs = case_inputs(c)
+    assert a.shape[1] == c["synth_prompt"][0] and t.shape[1] == c["synth_prompt"][1]
+    taps = {}
+    codes = orc.inference(text, np.array([text.shape[-1]]), a, t.shape[-1], top_k=1, prompt_language=pl, text_language=langs,
+                          force_eos_at=c["force_eos_at"], taps=taps)
+    np.testing.assert_array_equal(codes, g["codes"])
+    n = g["ar_logits"].shape[0]
+    np.testing.assert_allclose(np.stack([l.numpy() for l in taps["ar_logits"][:n]]), g["ar_logits"], atol=2e-4, rtol=0)
+    np.testing.assert_allclose(taps["nar_logits"][0][:16].numpy(), g["nar_logits0"], atol=5e-3, rtol=0)
