@@ -21,7 +21,7 @@ int main(int argc, char** argv) {
   printf("sizeof vx_config %zu\nsizeof vx_batch %zu\nsizeof vx_sampling %zu\n", sizeof(vx_config), sizeof(vx_batch), sizeof(vx_sampling));
   FIELD(vx_config, struct_size); FIELD(vx_config, num_layers); FIELD(vx_config, max_batch); FIELD(vx_config, max_text);
   FIELD(vx_config, max_prompt); FIELD(vx_config, max_new); FIELD(vx_config, use_graph); FIELD(vx_config, with_vocos);
-  FIELD(vx_config, debug_taps); FIELD(vx_config, with_encodec); FIELD(vx_config, cu_mask);
+  FIELD(vx_config, debug_taps); FIELD(vx_config, with_encodec); FIELD(vx_config, cu_mask); FIELD(vx_config, arith);
   FIELD(vx_batch, struct_size); FIELD(vx_batch, batch); FIELD(vx_batch, text_ids); FIELD(vx_batch, text_lang);
   FIELD(vx_batch, text_stride); FIELD(vx_batch, text_lens); FIELD(vx_batch, prompt_codes); FIELD(vx_batch, prompt_stride);
   FIELD(vx_batch, prompt_lens);
@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
   vx_config cfg;
   vx_ctx* ctx = NULL;
   memset(&cfg, 0, sizeof cfg);
-  cfg.struct_size = (uint32_t)(sizeof cfg - sizeof cfg.cu_mask);
+  cfg.struct_size = (uint32_t)(sizeof cfg - sizeof cfg.arith);      /* the ABI-3 struct, without `arith` */
   cfg.num_layers = 2; cfg.max_batch = 1; cfg.max_text = 8; cfg.max_prompt = 8; cfg.max_new = 8;
   int rc = vx_create(0, &cfg, &ctx);
   printf("short_struct rc %d msg %s\n", rc, vx_last_error(NULL));

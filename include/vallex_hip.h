@@ -32,7 +32,7 @@ typedef struct vx_ctx vx_ctx;
 /* ABI guard.  Every descriptor struct starts with `struct_size` = sizeof(that struct) as the CALLER compiled it; the library
  * rejects a mismatch with VX_EINVAL instead of reading past the end of a shorter (older) struct.  vx_abi_version() returns
  * VX_ABI_VERSION of the library that was actually loaded, so a binding can check it before the first call. */
-#define VX_ABI_VERSION 3
+#define VX_ABI_VERSION 4
 int32_t vx_abi_version(void);
 
 /* Model/arena geometry.  d_model=1024, 16 heads, FFN 4096, 8 codebooks are fixed by the kernels
@@ -51,7 +51,15 @@ typedef struct vx_config {
   uint32_t cu_mask[8];     /* all zero: the context's stream may use every CU.  Otherwise bit i of word i/32 enables CU i
                               (hipExtStreamCreateWithCUMask): contexts that SHARE one GPU get disjoint CU sets, so the
                               latency-bound decode of one batch runs beside the matrix-bound NAR stages of another */
+  int32_t arith;           /* arithmetic of the full-sequence projections and attention (AR prefill, NAR stages; the cached decode
+                              step is exact fp32 always): 0 = default (f16x2 unless the environment says otherwise:
+                              VX_GEMM_X3 / VX_GEMM_F32 / VX_ATTN_X3 / VX_ATTN_F32 = 1), VX_ARITH_F16X2, VX_ARITH_BF16X3,
+                              VX_ARITH_F32 (the reference's own arithmetic).  See vx_arith_mode / vx_last_fallbacks. */
 } vx_config;
+#define VX_ARITH_DEFAULT 0
+#define VX_ARITH_F16X2 1   /* operands split into fp16 head + tail (22 significant bits), fp32 accumulate, f16 MFMA */
+#define VX_ARITH_BF16X3 2  /* operands split into three bf16 terms (24 bits), fp32 accumulate, bf16 MFMA */
+#define VX_ARITH_F32 3     /* fp32 operands, fp32 MFMA */
 
 /* ---- lifetime -------------------------------------------------------------------------------------------
  * replaces: model construction + .to(device) in preload_models(), utils/generation.py:67-89 */
@@ -148,7 +156,8 @@ int64_t vx_read_tap(vx_ctx* ctx, const char* name, float* dst, int64_t max_float
 
 /* ---- measurement ------------------------------------------------------------------------------------------
  * HIP-event timing of kernel classes on the context's own stream (bench.py roofline leg).
- * which: 0 = dec_attn (KV streaming), 1 = skinny GEMMs, 2 = full-seq GEMM, 3 = full-seq attention.
+ * which: 0 = dec_attn (KV streaming), 1 = skinny GEMMs, 2 = transformer projections (full-sequence GEMMs), 3 = full-seq
+ * attention, 4 = the fp32 GEMMs of the Vocos / EnCodec heads.
  * vx_prof_enable(1) makes the AR step run un-graphed with an event pair around each launch of every class. */
 int vx_prof_enable(vx_ctx* ctx, int32_t on);
 int vx_prof_get(vx_ctx* ctx, int32_t which, double* total_ms, int64_t* launches, double* algo_bytes);
@@ -171,6 +180,16 @@ int vx_last_stats(vx_ctx* ctx, int64_t* ar_steps, int64_t* frames, double* ar_ms
  * rule -- EOS, or more than 16 * text_len frames (models/vallex.py:575-578) -- would have ended it.  0 = every row is what the
  * reference would have produced; > 0: create the context with a larger max_new. */
 int vx_last_truncated(vx_ctx* ctx, int32_t* rows);
+
+/* The f16x2 kernels need |activation|, |q|/8, |k|, |v| < 2047 (fp16 range at their fixed scale); the reference's fp32 path has
+ * no such bound (modules/transformer.py:371-373, modules/activation.py:144-166).  A phase (AR prefill of a micro-batch / the 7
+ * NAR stages of a micro-batch) whose operands leave that range is detected on the device and RE-RUN on the exact-fp32 kernels
+ * automatically; the call succeeds with the fp32 result.  This reports how many phases of the last vx_infer / vx_ar_prefill /
+ * vx_nar took that path, and the count since vx_create (any pointer may be NULL). */
+int vx_last_fallbacks(vx_ctx* ctx, int32_t* prefill_phases, int32_t* nar_phases, int64_t* lifetime_phases);
+
+/* the arithmetic the context actually runs (after vx_finalize_weights): gemm_mode / attn_mode = 0 f16x2, 1 bf16x3, 2 fp32 */
+int vx_arith_mode(vx_ctx* ctx, int32_t* gemm_mode, int32_t* attn_mode);
 
 #ifdef __cplusplus
 }

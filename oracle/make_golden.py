@@ -105,6 +105,39 @@ FULL_CASES = {
     "nl12_full_ja_topk10": dict(num_layers=12, seed=0, eos_gain=0.0, preset="cafe", n_text=100, lang="ja", top_k=10,
                                 force_eos_at=600, useed=3456, full=True, text_seed=5),
 }
+# Round 3 -- the regimes the six FULL_CASES do not reach (all 12 layers, bench weights unless stated):
+#  * TRAINED_CASES: weights with the statistics of a trained checkpoint (synth.trained_like_state_dict: heavy-tailed weights,
+#    LayerNorm gains U(0.5, 4), massive FFN channels / residual dimensions, decisive AR logits);
+#  * nl12_cap1024_en: S = 58 + 6 = 64 text ids, nothing ever emits EOS -> the run ends at the reference's own cap
+#    (models/vallex.py:575-578: y.shape[1] - prompts.shape[1] > 16 * x_lens.max()) with exactly 1024 frames, contexts to 1314
+#    (BASELINE config 3: "padded to 1024 codec tokens");
+#  * CHAIN_CASES: two consecutive sentences of generate_audio_from_long_text's sliding window (utils/generation.py:229-274):
+#    sentence 2 is prompted by ALL frames of sentence 1 (encoded_frames[:, :, -NUM_QUANTIZERS:] keeps every frame) and by its
+#    text (text_tokens[:, enroll_x_lens:]), the prompt LANGUAGE stays the first prompt's (lang_pr is never updated) ->
+#    S = 200, Tp = 563, contexts to 200 + 1 + 563 + 563 = 1327 (BASELINE config 5).
+TRAINED_CASES = {
+    "nl12_trained_en_greedy": dict(num_layers=12, seed=0, eos_gain=0.0, trained=True, preset="librispeech_1", n_text=100, lang="en",
+                                   top_k=1, force_eos_at=600, useed=None, full=True, text_seed=6),
+    "nl12_trained_zh_topk10": dict(num_layers=12, seed=0, eos_gain=0.0, trained=True, preset="paimon", n_text=100, lang="zh",
+                                   top_k=10, force_eos_at=600, useed=4567, full=True, text_seed=7),
+}
+LONG_CASES = {
+    "nl12_cap1024_en": dict(num_layers=12, seed=0, eos_gain=0.0, preset="librispeech_1", n_text=6, lang="en", top_k=1,
+                            force_eos_at=None, useed=None, full=True, text_seed=8),
+}
+CHAIN_FRAMES = 563             # 7.5 s per sentence (bench.py --long-text)
+CHAIN_CASES = {
+    # sentence 1: the paimon preset (zh) + 100 ids; sentence 2: built from sentence 1's output by chain_second()
+    "nl12_chain2_zh": dict(num_layers=12, seed=0, eos_gain=0.0, preset="paimon", n_text=100, lang="zh", top_k=10,
+                           force_eos_at=CHAIN_FRAMES, useed=5678, full=True, text_seed=9, text_seed2=10, useed2=6789),
+}
+# Operands outside the fp16 range of the f16x2 kernels, same function bit for bit (synth.out_of_range_state_dict): the base case's
+# golden must come out again.  (base case, kind)
+RANGE_CASES = {
+    "nl2_range_ffn": ("nl2_topk10", "ffn"),
+    "nl2_range_v": ("nl2_sharp_greedy", "v"),
+    "nl2_range_k": ("nl2_sharp_topk10", "k"),
+}
 FULL_LOGIT_EVERY = 50          # AR logits are stored for steps 0, 50, ..., 550 (+ the forced-EOS step is not stored)
 
 # Shapes and languages of ALL 41 reference presets (presets/*.npz: frames, prompt text ids, lang_code zh 0 / ja 1 / en 2) -- metadata
@@ -162,7 +195,36 @@ def case_inputs(c):
     return a, t, text, pl, langs
 
 
-def run_reference(c):
+def case_state_dict(c):
+    """the weights of a case (tests and the generator build them the same way)"""
+    if c.get("trained"):
+        return synth.trained_like_state_dict(c["num_layers"], c["seed"])
+    sd = synth.vallex_state_dict(c["num_layers"], c["seed"], c["eos_gain"], c.get("attn_gain", 1.0))
+    if c.get("range_kind"):
+        sd = synth.out_of_range_state_dict(sd, c["num_layers"], c["range_kind"])
+    return sd
+
+
+def all_cases():
+    """every named single-call case (name -> dict); RANGE_CASES are their base case + `range_kind`"""
+    out = {}
+    for grp in (CASES, SHARP_CASES, EDGE_CASES, FULL_CASES, TRAINED_CASES, LONG_CASES):
+        out.update(grp)
+    for name, (base, kind) in RANGE_CASES.items():
+        out[name] = dict(out[base], range_kind=kind)
+    return out
+
+
+def chain_second(c, codes1):
+    """inputs of sentence 2 of a CHAIN case from sentence 1's output (1, T, 8): utils/generation.py:264-266 -- audio prompt =
+    all generated frames, text prompt = sentence 1's own text, then the new sentence's ids; prompt language unchanged."""
+    a1, t1, text1, pl, langs = case_inputs(c)
+    own = text1[:, t1.shape[-1]:]
+    new = synth.synth_text(c["n_text"], c["text_seed2"])[None]
+    return np.asarray(codes1, np.int64), own, np.concatenate([own, new], -1), pl, langs
+
+
+def run_reference(c, inputs=None, useed=None):
     sys.path.insert(0, REF)
     sys.dont_write_bytecode = True
     import models.vallex as V
@@ -170,10 +232,12 @@ def run_reference(c):
 
     m = VALLE(1024, 16, c["num_layers"], norm_first=True, add_prenet=False, prefix_mode=1,
               share_embedding=True, nar_scale_factor=1.0, prepend_bos=True, num_quantizers=8).eval()
-    sd = synth.vallex_state_dict(c["num_layers"], c["seed"], c["eos_gain"], c.get("attn_gain", 1.0))
+    sd = case_state_dict(c)
     missing = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
-    a, t, text, pl, langs = case_inputs(c)
+    a, t, text, pl, langs = inputs if inputs is not None else case_inputs(c)
+    if useed is not None:
+        c = dict(c, useed=useed)
 
     full = bool(c.get("full"))
     rec = {"logits": [], "step": 0, "margin": []}
@@ -293,12 +357,32 @@ def main(only=None):
         out = run_reference_continual(c)
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
         print(name, out["codes"].shape, out["codes"][0, :4, 1], flush=True)
-    for name, c in list(CASES.items()) + list(SHARP_CASES.items()) + list(EDGE_CASES.items()) + list(FULL_CASES.items()):
+    import time
+    for name, c in CHAIN_CASES.items():
+        if not only or name not in only:
+            continue                                   # slow: only when named
+        t0 = time.time()
+        o1 = run_reference(c)
+        o2 = run_reference(c, inputs=chain_second(c, o1["codes"]), useed=c["useed2"])
+        out = dict(codes1=o1["codes"], **o2)
+        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+        print(name, o1["codes"].shape, "->", o2["codes"].shape, f"{time.time() - t0:.1f}s min AR margin {o2['ar_margin'].min():.3e}, "
+              f"min NAR margin {o2['nar_margin'].min():.3e}", flush=True)
+    for name, (base, kind) in RANGE_CASES.items():
+        if not only or name not in only:
+            continue
+        # no new fixture: the rescaled weights are the same function, the LIVE reference must return the base golden
+        out = run_reference(dict(all_cases()[name]))
+        gold = np.load(os.path.join(GOLD, base + ".npz"))
+        assert np.array_equal(out["codes"], gold["codes"]), (name, "live reference differs from the base golden")
+        print(name, "live reference == golden of", base, "| max |logit diff|", float(np.abs(out["ar_logits"] - gold["ar_logits"]).max()),
+              flush=True)
+    for name, c in (list(CASES.items()) + list(SHARP_CASES.items()) + list(EDGE_CASES.items()) + list(FULL_CASES.items())
+                    + list(TRAINED_CASES.items()) + list(LONG_CASES.items())):
         if only and name not in only:
             continue
         if c.get("full") and not only and os.path.exists(os.path.join(GOLD, name + ".npz")):
             continue                                   # full-length runs are slow: regenerate only when named
-        import time
         t0 = time.time()
         out = run_reference(c)
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)

@@ -131,6 +131,95 @@ def vallex_state_dict(num_layers: int = 12, seed: int = 0, eos_gain: float = 1.0
     return sd
 
 
+def _layer_prefixes(num_layers):
+    return [f"{w}_decoder.layers.{i}." for w in ("ar", "nar") for i in range(num_layers)]
+
+
+def trained_like_state_dict(num_layers: int = 12, seed: int = 0, logit_gain: float = 6.0,
+                            emb_offset: float = 2.0, massive_bias: float = 4.0, ln_hi: float = 4.0) -> "OrderedDict[str, np.ndarray]":
+    """A state-dict with the STATISTICS of a trained checkpoint (utils/generation.py:79-83 loads one; it is not available
+    offline), derived from `vallex_state_dict(num_layers, seed, eos_gain=0)` by a second, independent RNG stream -- the base
+    stream and with it every other fixture stays what it was.  What the default init lacks and this adds:
+      * heavy-tailed weights: every projection matrix is multiplied element-wise by a log-normal factor (sigma 0.45, rms kept)
+        and 1 element in 4096 by a further 8 (outlier weights);
+      * LayerNorm gains ~ U(0.5, 4) and biases ~ U(-0.5, 0.5) on every norm (plain and adaptive): Q/K/V and the FFN inputs are
+        2-3x larger, the attention scores ~6x (peaky softmax);
+      * massive FFN channels: three hidden units per layer with 24x the input weights and a positive bias (mostly on,
+        activations of a few hundred), read out with 0.25x weights;
+      * massive residual dimensions: two embedding columns carry a constant offset in every token table;
+      * decisive AR logits: ar_predict_layer x logit_gain (logit std ~9, median top-2 gap ~2 >> fp32 noise).
+    (Stronger settings -- offset 12, bias 20, gain 16 -- collapse greedy decoding into 2-cycles of ~10 distinct ids; these keep
+    the statistics and some variety.)
+    The EOS row stays zero (eos_gain 0), so runs end at the forced step only."""
+    sd = vallex_state_dict(num_layers, seed, eos_gain=0.0)
+    rng = np.random.default_rng(770_000 + seed)
+    d = D_MODEL
+    keep_rms = np.float32(math.exp(-0.45 * 0.45))            # E[exp(2 * 0.45 z)] ** -0.5
+    for p in _layer_prefixes(num_layers):
+        for name in ("self_attn.in_proj_weight", "self_attn.out_proj.weight", "linear1.weight", "linear2.weight"):
+            w = sd[p + name]
+            w *= np.exp(0.45 * rng.standard_normal(w.shape)).astype(np.float32) * keep_rms
+            out = rng.random(w.shape) < (1.0 / 4096.0)
+            w[out] *= np.float32(8.0)
+        ch = rng.choice(D_FF, size=3, replace=False)
+        sd[p + "linear1.weight"][ch] *= np.float32(24.0)
+        sd[p + "linear1.bias"][ch] = np.abs(sd[p + "linear1.bias"][ch]) * np.float32(24.0) + np.float32(massive_bias)
+        sd[p + "linear2.weight"][:, ch] *= np.float32(0.25)
+        adaptive = p.startswith("nar")
+        for n in ("norm1", "norm2"):
+            q = p + n + (".norm" if adaptive else "")
+            sd[q + ".weight"][:] = rng.uniform(0.5, ln_hi, size=d).astype(np.float32)
+            sd[q + ".bias"][:] = rng.uniform(-0.5, 0.5, size=d).astype(np.float32)
+    for q in ("ar_decoder.norm", "nar_decoder.norm.norm"):
+        sd[q + ".weight"][:] = rng.uniform(0.5, ln_hi, size=d).astype(np.float32)
+        sd[q + ".bias"][:] = rng.uniform(-0.5, 0.5, size=d).astype(np.float32)
+    cols = rng.choice(d, size=2, replace=False)
+    seen = set()
+    for k, v in sd.items():
+        if "embedding" in k and "stage" not in k and v.ndim == 2 and v.shape[1] == d and id(v) not in seen:
+            seen.add(id(v))                                   # tied tables (nar_predict_layers.j) are the same array object
+            v[:, cols] += np.float32(emb_offset)
+    sd["ar_predict_layer.weight"] *= np.float32(logit_gain)
+    return sd
+
+
+def out_of_range_state_dict(sd: "OrderedDict[str, np.ndarray]", num_layers: int, kind: str, gain_log2: int = 12,
+                            stacks=("ar", "nar")) -> "OrderedDict[str, np.ndarray]":
+    """The SAME function as `sd`, bit for bit in fp32, with operands that leave the fp16 range of the f16x2 kernels
+    (|x| >= 2047): power-of-two rescalings that cancel exactly --
+      'ffn': the first 64 hidden units of every layer: linear1 rows and biases x 2^g, the matching linear2 columns x 2^-g
+             (relu(2^g a) 2^-g w == relu(a) w exactly: power-of-two scaling commutes with every fp32 rounding) -> hidden
+             activations of ~5000 (modules/transformer.py:371-373 puts no bound on them);
+      'v':   head 0: the V rows of in_proj (weights and biases) x 2^g, the out_proj columns of that head x 2^-g -> |v| ~ 3000;
+      'k':   head 1: the K rows x 2^g, the Q rows x 2^-g (q.k unchanged) -> |k| ~ 3000.
+    A correct engine therefore returns exactly the ids of the unscaled model; the reference does (oracle/make_golden.py
+    checks it on the live reference)."""
+    out = OrderedDict()
+    copied = {}
+    for k, v in sd.items():                                   # keep the tying (same array object under two keys)
+        copied.setdefault(id(v), v.copy())
+        out[k] = copied[id(v)]
+    up, dn = np.float32(2.0 ** gain_log2), np.float32(2.0 ** -gain_log2)
+    d = D_MODEL
+    for p in [q for q in _layer_prefixes(num_layers) if q.split("_")[0] in stacks]:
+        if kind == "ffn":
+            out[p + "linear1.weight"][:64] *= up
+            out[p + "linear1.bias"][:64] *= up
+            out[p + "linear2.weight"][:, :64] *= dn
+        elif kind == "v":
+            out[p + "self_attn.in_proj_weight"][2 * d: 2 * d + 64] *= up
+            out[p + "self_attn.in_proj_bias"][2 * d: 2 * d + 64] *= up
+            out[p + "self_attn.out_proj.weight"][:, :64] *= dn
+        elif kind == "k":
+            out[p + "self_attn.in_proj_weight"][d + 64: d + 128] *= up
+            out[p + "self_attn.in_proj_bias"][d + 64: d + 128] *= up
+            out[p + "self_attn.in_proj_weight"][64:128] *= dn
+            out[p + "self_attn.in_proj_bias"][64:128] *= dn
+        else:
+            raise ValueError(kind)
+    return out
+
+
 def vocos_state_dict(seed: int = 2) -> "OrderedDict[str, np.ndarray]":
     """Synthetic weights in the key layout of `charactr/vocos-encodec-24khz`
     (recalled from the pip `vocos` package, SURVEY.md §A.5 -- parity unpinned)."""

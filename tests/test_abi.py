@@ -32,7 +32,7 @@ def test_struct_layout_matches_header():
     from vallex_amd._capi import vx_batch, vx_config, vx_sampling
     # every descriptor starts with struct_size (ABI guard, include/vallex_hip.h)
     assert vx_config.struct_size.offset == vx_batch.struct_size.offset == vx_sampling.struct_size.offset == 0
-    assert vx_config.cu_mask.offset == 10 * 4 and C.sizeof(vx_config) == 18 * 4
+    assert vx_config.cu_mask.offset == 10 * 4 and vx_config.arith.offset == 18 * 4 and C.sizeof(vx_config) == 19 * 4
     assert vx_batch.text_ids.offset == 8 and vx_batch.text_lens.offset == 32 and C.sizeof(vx_batch) == 64
     assert vx_sampling.uniforms.offset == 16 and vx_sampling.seed.offset == 32 and vx_sampling.best_of.offset == 48
     assert C.sizeof(vx_sampling) == 64
@@ -56,7 +56,7 @@ def test_abi_version_and_struct_size_guard(lib):
     hdr = open(os.path.join(ROOT, "include", "vallex_hip.h")).read()
     assert int(re.search(r"#define VX_ABI_VERSION (\d+)", hdr).group(1)) == ABI_VERSION == lib.vx_abi_version()
     ctx = C.c_void_p()
-    short = vx_config(C.sizeof(vx_config) - 32, 2, 1, 8, 8, 8, 1, 0, 0, 0)         # e.g. the ABI-2 struct without `cu_mask`
+    short = vx_config(C.sizeof(vx_config) - 4, 2, 1, 8, 8, 8, 1, 0, 0, 0)          # e.g. the ABI-3 struct without `arith`
     assert lib.vx_create(0, C.byref(short), C.byref(ctx)) == VX_EINVAL
     assert b"struct_size" in lib.vx_last_error(None)
 

@@ -1,0 +1,76 @@
+"""GPU: operands outside the fp16 range of the f16x2 kernels (|activation|, |q|/8, |k|, |v| >= 2047).
+
+The reference computes in fp32 and puts no bound on the FFN hidden activations (modules/transformer.py:371-373) or on q / k / v
+(modules/activation.py:144-166).  `synth.out_of_range_state_dict` rescales channels by 2^12 and their read-out by 2^-12: in fp32
+that is THE SAME function bit for bit (oracle/make_golden.py RANGE_CASES: the live reference returns the base case's golden, logit
+difference 0.0), but the hidden activations / values / keys are now ~3000-5000.  The engine must notice on the device, re-run
+the affected phase on the exact-fp32 kernels by itself and return the reference's ids -- the call must not fail, and must not
+need an environment variable."""
+import numpy as np
+import pytest
+
+from oracle.make_golden import RANGE_CASES, all_cases
+from tests._util import assert_codes, case_model, golden, inputs_row
+
+pytestmark = pytest.mark.gpu
+
+ALL = all_cases()
+
+
+def _run(m, c, rows, us):
+    return m.inference_batch(rows, top_k=c["top_k"], temperature=c.get("temperature", 1.0),
+                             uniforms=None if us is None else us, force_eos_at=c["force_eos_at"])
+
+
+@pytest.mark.parametrize("name", sorted(RANGE_CASES))
+def test_out_of_range_operands_fall_back_to_fp32(name):
+    base, kind = RANGE_CASES[name]
+    c = ALL[name]
+    row, us = inputs_row(c)
+    m = case_model(c)                                   # default arithmetic: f16x2 projections + attention
+    assert m.engine.arith_mode() == ("f16x2", "f16x2")
+    out = _run(m, c, [row], None if us is None else us[:, None])[0]
+    fb = m.engine.last_fallbacks()
+    assert fb["prefill"] >= 1 and fb["nar"] >= 1, (name, fb)      # both stacks carry the rescaled channels
+    assert_codes(name, out, golden(base))
+    # the same row next to an ordinary-length second row (two rows per call), and once more: the flag was cleared
+    row2 = dict(row, text=row["text"][: max(row["enroll"] + 3, len(row["text"]) - 4)])
+    us2 = None if us is None else np.stack([us, us[::-1]], axis=1)
+    outs = _run(m, c, [row, row2], us2)
+    assert_codes(name + " (row 0 of 2)", outs[0], golden(base))
+    assert m.engine.last_fallbacks()["prefill"] >= 1
+
+
+def test_only_the_phase_that_needs_it_is_rerun():
+    """AR stack rescaled, NAR stack untouched (and vice versa): exactly that phase falls back"""
+    from oracle import synth
+    from tests import _util
+    base, kind = RANGE_CASES["nl2_range_ffn"]
+    c = ALL[base]
+    row, us = inputs_row(c)
+    sd = synth.vallex_state_dict(c["num_layers"], c["seed"], c["eos_gain"])
+    for stacks, want in ((("ar",), (1, 0)), (("nar",), (0, 1))):
+        m = _util.VALLE(1024, 16, c["num_layers"], norm_first=True, add_prenet=False, prefix_mode=1, share_embedding=True,
+                        nar_scale_factor=1.0, prepend_bos=True, num_quantizers=8, engine_max_new=320, engine_max_prompt=400,
+                        engine_max_text=256, engine_max_batch=4)
+        m.to("cuda:0").load_state_dict(synth.out_of_range_state_dict(sd, c["num_layers"], kind, stacks=stacks), strict=True)
+        out = _run(m, c, [row], None if us is None else us[:, None])[0]
+        fb = m.engine.last_fallbacks()
+        assert (fb["prefill"], fb["nar"]) == want, (stacks, fb)
+        assert_codes(f"{base} / {stacks}", out, golden(base))
+
+
+def test_in_range_weights_never_fall_back_and_fp32_mode_has_no_guard():
+    base, kind = RANGE_CASES["nl2_range_v"]
+    c = ALL[base]
+    row, us = inputs_row(c)
+    m = case_model(c)
+    out = _run(m, c, [row], None if us is None else us[:, None])[0]
+    assert m.engine.last_fallbacks() == dict(prefill=0, nar=0, lifetime=0)
+    assert_codes(base, out, golden(base))
+    c2 = ALL["nl2_range_v"]
+    m32 = case_model(c2, arith="f32")
+    assert m32.engine.arith_mode() == ("f32", "f32")
+    out = _run(m32, c2, [row], None if us is None else us[:, None])[0]
+    assert m32.engine.last_fallbacks()["lifetime"] == 0
+    assert_codes("nl2_range_v in fp32 mode", out, golden(base))

@@ -1,0 +1,48 @@
+"""GPU: weights with the statistics of a TRAINED checkpoint (the real vallex-checkpoint.pt of utils/generation.py:79-83 is not
+available offline): heavy-tailed projection weights, LayerNorm gains U(0.5, 4), massive FFN channels and residual dimensions,
+decisive AR logits (oracle/synth.py: trained_like_state_dict).  Two 12-layer, 600-frame runs of the LIVE reference on them
+(oracle/make_golden.py TRAINED_CASES) must come back bit for bit in every arithmetic of the full-sequence path -- f16x2 (the
+default), bf16x3 and exact fp32 -- and the default must get there WITHOUT falling back to fp32 (the operands of these weights
+stay inside the fp16 range: the format's margin, not the fallback, carries them)."""
+import numpy as np
+import pytest
+
+from oracle.make_golden import FULL_LOGIT_EVERY, TRAINED_CASES
+from tests._util import assert_codes, case_model, golden, inputs_row, nar_logit_error, teacher_forced_logit_error
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(max_new=608, max_prompt=400, max_text=256, max_batch=4)
+# abs tolerances on logits with std ~9 (AR) / ~45 (NAR) and |max| ~40 / ~250: ~1e-5 relative, the fp32 reassociation noise
+AR_TOL, NAR_TOL = 3e-3, 3e-2
+
+
+@pytest.mark.parametrize("arith", ["f16x2", "bf16x3", "f32"])
+@pytest.mark.parametrize("name", sorted(TRAINED_CASES))
+def test_trained_like_weights_match_the_live_reference(name, arith):
+    c = TRAINED_CASES[name]
+    g = golden(name)
+    row, us = inputs_row(c)
+    m = case_model(c, arith=arith, **KW)
+    assert m.engine.arith_mode() == (arith, arith)
+    out = m.inference_batch([row], top_k=c["top_k"], uniforms=None if us is None else us[:, None],
+                            force_eos_at=c["force_eos_at"])[0]
+    fb = m.engine.last_fallbacks()
+    assert_codes(f"{name} [{arith}]", out, g)
+    assert fb["prefill"] == 0 and fb["nar"] == 0, f"{arith}: the run needed the fp32 fallback {fb}"
+
+
+@pytest.mark.parametrize("arith", ["f16x2", "f32"])
+def test_trained_like_logits(arith):
+    name = "nl12_trained_en_greedy"
+    c = TRAINED_CASES[name]
+    g = golden(name)
+    row, _ = inputs_row(c)
+    m = case_model(c, arith=arith, debug_taps=True, **KW)
+    worst, flips = teacher_forced_logit_error(m, row, g, FULL_LOGIT_EVERY)
+    assert flips == 0, f"{flips} of 600 greedy decisions differ (min reference margin {g['ar_margin'].min():.2e})"
+    assert worst <= AR_TOL, worst
+    codes, errs = nar_logit_error(m, row, g)
+    assert max(errs) <= NAR_TOL, errs
+    np.testing.assert_array_equal(codes, g["codes"][0])
+    print(f"{name} [{arith}]: AR max |logit - ref| {worst:.2e}; NAR per stage {['%.1e' % e for e in errs]}")

@@ -162,3 +162,85 @@ def test_oracle_matches_reference_on_smallest_inputs(name):
     n = g["ar_logits"].shape[0]
     np.testing.assert_allclose(np.stack([l.numpy() for l in taps["ar_logits"][:n]]), g["ar_logits"], atol=2e-4, rtol=0)
     np.testing.assert_allclose(taps["nar_logits"][0][:16].numpy(), g["nar_logits0"], atol=5e-3, rtol=0)
+
+
+# ---- round 3: operands beyond the fp16 range, trained-like weights, the 16*S cap at 1024 frames, the sliding-window chain ----
+def _run_case(c, inputs=None, useed="case", taps=None):
+    from oracle.make_golden import case_state_dict
+    orc = VallexOracle(case_state_dict(c), c["num_layers"])
+    a, t, text, pl, langs = inputs if inputs is not None else case_inputs(c)
+    useed = c["useed"] if useed == "case" else useed
+    us = None if useed is None else synth.uniforms(4096, 1, useed)[:, 0]
+    return orc.inference(text, np.array([text.shape[-1]]), a, t.shape[-1], top_k=c["top_k"], temperature=c.get("temperature", 1.0),
+                         prompt_language=pl, text_language=langs, uniforms=us, force_eos_at=c["force_eos_at"], taps=taps)
+
+
+def test_out_of_range_rescaling_is_the_same_function():
+    """synth.out_of_range_state_dict (channels x 2^12, read-out x 2^-12) does not change ONE bit of the fp32 function: the
+    oracle on the rescaled weights reproduces the base golden's ids and its logits exactly (the live reference does too:
+    oracle/make_golden.py RANGE_CASES, difference 0.0) -- while the hidden activations / values / keys are now far outside
+    fp16 range (what tests/test_gpu_range_fallback.py needs)."""
+    from oracle.make_golden import RANGE_CASES, all_cases, case_state_dict
+    import torch
+    for name, (base, kind) in sorted(RANGE_CASES.items()):
+        c = all_cases()[name]
+        t_new, t_old = {}, {}
+        codes = _run_case(c, taps=t_new)
+        np.testing.assert_array_equal(codes, np.load(os.path.join(GOLD, base + ".npz"))["codes"], err_msg=name)
+        _run_case(all_cases()[base], taps=t_old)
+        for x, y in zip(t_new["ar_logits"], t_old["ar_logits"]):
+            assert torch.equal(x, y), name
+        sd = case_state_dict(c)
+        if kind == "ffn":
+            assert np.abs(sd["ar_decoder.layers.0.linear1.weight"][:64]).max() > 100.0
+    # the rescaled operands really are out of range: |relu(W1 LN(x) + b1)| for a unit-variance row
+    x = torch.randn(64, 1024)
+    w = torch.from_numpy(case_state_dict(all_cases()["nl2_range_ffn"])["nar_decoder.layers.0.linear1.weight"])
+    assert float((x @ w.T).abs().max()) > 2047.0
+
+
+SLOW = os.environ.get("VX_SLOW") == "1"
+
+
+@pytest.mark.skipif(not SLOW, reason="12 layers x 600-1024 frames on the CPU oracle: ~1 min each; VX_SLOW=1 (the GPU suite runs all of them)")
+@pytest.mark.parametrize("name", ["nl12_trained_en_greedy", "nl12_trained_zh_topk10", "nl12_cap1024_en"])
+def test_oracle_matches_reference_round3_long(name):
+    from oracle.make_golden import LONG_CASES, TRAINED_CASES
+    c = dict(TRAINED_CASES, **LONG_CASES)[name]
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    taps = {}
+    codes = _run_case(c, taps=taps)
+    np.testing.assert_array_equal(codes, g["codes"])
+    ar = np.stack([taps["ar_logits"][i].numpy() for i in range(0, min(len(taps["ar_logits"]), g["codes"].shape[1] + 1), FULL_LOGIT_EVERY)])
+    scale = max(1.0, float(np.abs(g["ar_logits"]).max()))
+    np.testing.assert_allclose(ar, g["ar_logits"][: len(ar)], atol=2e-4 * scale, rtol=0)
+
+
+@pytest.mark.skipif(not SLOW, reason="two 12-layer 563-frame oracle runs; VX_SLOW=1")
+def test_oracle_matches_reference_sliding_window_chain():
+    from oracle.make_golden import CHAIN_CASES, chain_second
+    c = CHAIN_CASES["nl12_chain2_zh"]
+    g = np.load(os.path.join(GOLD, "nl12_chain2_zh.npz"))
+    c1 = _run_case(c)
+    np.testing.assert_array_equal(c1, g["codes1"])
+    np.testing.assert_array_equal(_run_case(c, inputs=chain_second(c, c1), useed=c["useed2"]), g["codes"])
+
+
+def test_round3_fixture_shapes():
+    """what the committed fixtures hold (cheap; the content is compared on the GPU and, with VX_SLOW=1, by the oracle)"""
+    from oracle.make_golden import CHAIN_CASES, CHAIN_FRAMES, LONG_CASES, TRAINED_CASES, chain_second
+    g = np.load(os.path.join(GOLD, "nl12_cap1024_en.npz"))
+    c = LONG_CASES["nl12_cap1024_en"]
+    a, t, text, pl, langs = case_inputs(c)
+    assert text.shape[-1] == 64 and g["codes"].shape == (1, 16 * 64, 8)          # models/vallex.py:575-578
+    assert g["ar_logits"].shape == (1024 // FULL_LOGIT_EVERY + 1, 1025) and g["nar_logits"].shape == (7, 16, 1024)
+    assert int(g["codes"].max()) < 1024
+    g = np.load(os.path.join(GOLD, "nl12_chain2_zh.npz"))
+    c = CHAIN_CASES["nl12_chain2_zh"]
+    a2, t2, text2, pl2, _ = chain_second(c, g["codes1"])
+    assert g["codes1"].shape == g["codes"].shape == (1, CHAIN_FRAMES, 8)
+    assert a2.shape == (1, CHAIN_FRAMES, 8) and t2.shape == (1, 100) and text2.shape == (1, 200) and pl2 == "zh"
+    assert text2.shape[-1] + 1 + 2 * CHAIN_FRAMES == 1327                        # longest decode context
+    for n in TRAINED_CASES:
+        g = np.load(os.path.join(GOLD, n + ".npz"))
+        assert g["codes"].shape == (1, 600, 8) and float(np.abs(g["ar_logits"]).max()) > 20.0      # decisive logits

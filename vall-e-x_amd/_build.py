@@ -36,23 +36,26 @@ def _digest(paths, extra=()) -> str:
 
 
 def _stale(target: str, deps, extra=()) -> bool:
-    """Content-keyed, not mtime-keyed: an object is reused only if the digest of its source, the headers and the flags equals
-    the one recorded when it was compiled (`<target>.sha256`); a stale or foreign .o/.so that travelled with a snapshot is
-    rebuilt."""
+    """Content-keyed, not mtime-keyed: an object is reused only if (a) the digest of its source, the headers and the flags
+    equals the one recorded when it was compiled and (b) the digest of the object ITSELF equals the one recorded right after
+    the compiler wrote it (`<target>.sha256` holds both) -- a stale or foreign .o/.so that travelled with a snapshot is rebuilt
+    even if somebody copied a matching source stamp next to it.  VX_FORCE_BUILD=1 rebuilds everything."""
     stamp = target + ".sha256"
     if not os.path.exists(target) or not os.path.exists(stamp):
         return True
-    return open(stamp).read().strip() != _digest(deps, extra)
+    rec = open(stamp).read().split()
+    return len(rec) != 2 or rec[0] != _digest(deps, extra) or rec[1] != _digest([target])
 
 
 def _stamp(target: str, deps, extra=()):
     with open(target + ".sha256", "w") as f:
-        f.write(_digest(deps, extra))
+        f.write(_digest(deps, extra) + " " + _digest([target]))
 
 
 def build_library(force: bool = False, verbose: bool = False, dev: bool = False) -> str:
     """dev=True: a SEPARATE library with the kernels' timing probes compiled in (-DVX_DEV_PROBES), for tools/gemm_bench.py and
     tools/attn_bench.py only (tools/dev/libvallex_hip.so); the product library never contains them."""
+    force = force or os.environ.get("VX_FORCE_BUILD", "") == "1"
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
     out_dir = os.path.join(os.path.dirname(HERE), "tools", "dev") if dev else CSRC
@@ -81,7 +84,7 @@ def build_library(force: bool = False, verbose: bool = False, dev: bool = False)
     if force or jobs or _stale(lib, objs):
         run(([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, lib, objs))
         relinked = True
-    print(f"[build] {len(jobs)} of {len(SOURCES)} sources compiled for gfx950, library {'linked' if relinked else 'up to date (content digests match)'}",
+    print(f"[build] {len(jobs)} of {len(SOURCES)} sources compiled for gfx950, library {'linked' if relinked else 'up to date (source AND object digests match)'}",
           flush=True)
     return lib
 

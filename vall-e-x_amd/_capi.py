@@ -27,7 +27,7 @@ class vx_config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("num_layers", C.c_int32), ("max_batch", C.c_int32), ("max_text", C.c_int32),
                 ("max_prompt", C.c_int32), ("max_new", C.c_int32), ("use_graph", C.c_int32),
                 ("with_vocos", C.c_int32), ("debug_taps", C.c_int32), ("with_encodec", C.c_int32),
-                ("cu_mask", C.c_uint32 * 8)]
+                ("cu_mask", C.c_uint32 * 8), ("arith", C.c_int32)]
 
 
 class vx_batch(C.Structure):
@@ -45,12 +45,13 @@ class vx_sampling(C.Structure):
 
 
 # every symbol include/vallex_hip.h declares (tests/test_abi.py checks the library exports exactly these)
-ABI_VERSION = 3       # VX_ABI_VERSION of include/vallex_hip.h this binding was written against
+ABI_VERSION = 4       # VX_ABI_VERSION of include/vallex_hip.h this binding was written against
 
 SYMBOLS = ["vx_abi_version", "vx_create", "vx_destroy", "vx_last_error", "vx_synchronize", "vx_load_tensor", "vx_finalize_weights",
            "vx_infer", "vx_vocos_decode", "vx_encodec_decode", "vx_encodec_encode", "vx_ar_prefill", "vx_ar_logits", "vx_ar_step",
            "vx_nar", "vx_read_tap",
-           "vx_prof_enable", "vx_prof_get", "vx_prof_reset", "vx_bench_kernel", "vx_bench_gemm", "vx_bench_attn", "vx_last_stats", "vx_last_truncated"]
+           "vx_prof_enable", "vx_prof_get", "vx_prof_reset", "vx_bench_kernel", "vx_bench_gemm", "vx_bench_attn", "vx_last_stats", "vx_last_truncated",
+           "vx_last_fallbacks", "vx_arith_mode"]
 
 _lib = None
 
@@ -98,6 +99,8 @@ def load_library() -> C.CDLL:
     lib.vx_bench_attn.argtypes = [ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P(C.c_double), P(C.c_double)]
     lib.vx_last_stats.argtypes = [ctx, P(C.c_int64), P(C.c_int64), P(C.c_double), P(C.c_double)]
     lib.vx_last_truncated.argtypes = [ctx, P(C.c_int32)]
+    lib.vx_last_fallbacks.argtypes = [ctx, P(C.c_int32), P(C.c_int32), P(C.c_int64)]
+    lib.vx_arith_mode.argtypes = [ctx, P(C.c_int32), P(C.c_int32)]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("vx_destroy", "vx_last_error", "vx_read_tap", "vx_abi_version"):
@@ -133,6 +136,9 @@ class Batch:
                           _ptr(self.prompt_lens, C.c_int32))
 
 
+ARITH = {"default": 0, "f16x2": 1, "bf16x3": 2, "f32": 3}      # vx_config.arith
+
+
 def cu_partition(n: int, total: int = 256):
     """CU masks of `n` contexts that share one GPU: contiguous, disjoint blocks of total // n CUs each."""
     per = total // max(1, n)
@@ -145,11 +151,12 @@ class Engine:
 
     def __init__(self, device_id: int = 0, num_layers: int = 12, max_batch: int = 32, max_text: int = 512,
                  max_prompt: int = 2048, max_new: int = 2048, use_graph: bool = True, with_vocos: bool = True,
-                 debug_taps: bool = False, with_encodec: bool = False, cu_mask: int = 0):
+                 debug_taps: bool = False, with_encodec: bool = False, cu_mask: int = 0, arith: int = 0):
+        """arith: 0 default (f16x2 unless VX_GEMM_* / VX_ATTN_* say otherwise), 1 f16x2, 2 bf16x3, 3 fp32 (ARITH)."""
         self.lib = load_library()
         words = (C.c_uint32 * 8)(*[(int(cu_mask) >> (32 * w)) & 0xFFFFFFFF for w in range(8)])
         self.cfg = vx_config(C.sizeof(vx_config), num_layers, max_batch, max_text, max_prompt, max_new, int(use_graph), int(with_vocos),
-                             int(debug_taps), int(with_encodec), words)
+                             int(debug_taps), int(with_encodec), words, int(arith))
         self.ctx = C.c_void_p()
         rc = self.lib.vx_create(device_id, C.byref(self.cfg), C.byref(self.ctx))
         if rc != VX_OK:
@@ -320,6 +327,19 @@ class Engine:
         us, md = C.c_double(), C.c_double()
         self._chk(self.lib.vx_bench_attn(self.ctx, batch, length, int(causal), variant, reps, C.byref(us), C.byref(md)))
         return us.value, md.value
+
+    def last_fallbacks(self):
+        """phases of the last call that left the fp16 range of the f16x2 kernels and were re-run in fp32 (+ lifetime count)"""
+        p, n, t = C.c_int32(), C.c_int32(), C.c_int64()
+        self._chk(self.lib.vx_last_fallbacks(self.ctx, C.byref(p), C.byref(n), C.byref(t)))
+        return dict(prefill=p.value, nar=n.value, lifetime=t.value)
+
+    def arith_mode(self):
+        """(gemm, attention) arithmetic of the full-sequence path: 'f16x2' | 'bf16x3' | 'f32' each"""
+        g, a = C.c_int32(), C.c_int32()
+        self._chk(self.lib.vx_arith_mode(self.ctx, C.byref(g), C.byref(a)))
+        names = ("f16x2", "bf16x3", "f32")
+        return names[g.value], names[a.value]
 
     def last_stats(self):
         a, f, am, nm = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()

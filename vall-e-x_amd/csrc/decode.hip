@@ -766,6 +766,7 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
   const bool act = a.active[b] != 0;
   if (!act && !a.logits_out) return;
   const int ngen = a.n_gen[b], pos = a.cur_pos[b], ctx = a.ctx_len[b], tlen = a.text_len[b], slot = a.slot_of[b];
+  const unsigned long long seed = a.uniforms ? 0ull : a.seed_dev[0];      // independent load, issued with the row state
 
   {
     // all SPL x SK loads are independent and issued together (SK is a compile-time constant and the tail index is clamped,
@@ -796,7 +797,7 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
   float u;
   if (a.uniforms) u = a.uniforms[(long)ngen * a.uniforms_stride + b];
   else   // counter-based: seed, row and step each pass through their own mixing round (no (seed, row) aliasing)
-    u = (float)(splitmix64(splitmix64(splitmix64(a.seed) + (unsigned long long)b) + (unsigned long long)ngen) >> 40) *
+    u = (float)(splitmix64(splitmix64(splitmix64(seed) + (unsigned long long)b) + (unsigned long long)ngen) >> 40) *
         (1.0f / 16777216.0f);
   f32x4 pe4[4], gg[4], be[4];
   float alpha = 0.f;

@@ -76,7 +76,11 @@ struct vx_ctx {
   int gemm_mode = 0;
   bool attn_x3 = true;                        // 16-bit-plane attention (h2 or x3); VX_ATTN_F32=1 keeps the fp32 MFMA kernel
   bool attn_h2 = true;                        // f16x2 attention (attn_full_h2.hip); VX_ATTN_X3=1: bf16x3 (attn_full_x3.hip)
-  int* range_flag = nullptr;       // device flag: an operand of an f16x2 GEMM did not fit fp16 (checked after every phase)
+  int* range_flag = nullptr;       // device flag: an operand of an f16x2 GEMM / attention did not fit fp16 (read at the phase's
+                                   // existing host sync; a raised flag re-runs the phase on the exact-fp32 kernels)
+  unsigned long long* seed_dev = nullptr;   // seed of the counter-based sampler (device word: not part of the captured graph)
+  int st_fb_prefill = 0, st_fb_nar = 0;     // phases of the last call that were re-run in fp32 (vx_last_fallbacks)
+  long fb_total = 0;                        // ... since the context was created
   unsigned short* fa3b = nullptr;  // second plane buffer: linear1 writes linear2's A planes straight from its epilogue (f16x2 mode)
   unsigned short* fa3 = nullptr;   // activation planes [2 or 3][M][K<=4096]
   unsigned short* pred_w3[N_Q - 1] = {};
@@ -112,7 +116,7 @@ struct vx_ctx {
 
   // profiling / stats
   int prof_on = 0;                 // 0 off, 1 every class (AR step runs eagerly), 2 full-sequence classes only
-  ProfClass prof[4];
+  ProfClass prof[5];
   int64_t st_steps = 0, st_frames = 0;
   int st_truncated = 0;            // rows of the last vx_infer cut by the arena (max_new) before the reference's stop rule
   double st_ar_ms = 0, st_nar_ms = 0;
@@ -236,12 +240,12 @@ int tap_store(vx_ctx* c, const std::string& name, const float* src, size_t n) {
 
 // ---- dense helpers -----------------------------------------------------------------------------------------
 void gemm(vx_ctx* c, const float* A, int lda, const float* Wt, int ldw, const float* bias, const float* resid, int ldr,
-          const float* colscale, float* C, int ldc, long M, int N, int K, int act, const int* gather = nullptr) {
+          const float* colscale, float* C, int ldc, long M, int N, int K, int act, const int* gather = nullptr, int cls = 4) {
   GemmArgs g{};
   g.A = A; g.lda = lda; g.W = Wt; g.ldw = ldw; g.bias = bias; g.resid = resid; g.ldr = ldr; g.colscale = colscale;
   g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.act = act; g.row_gather = gather;
-  ProfScope ps(c, 2);
-  if (c->prof_on) c->prof[2].bytes += 2.0 * (double)M * N * K;      // flops for this class
+  ProfScope ps(c, cls);               // class 2 = transformer projections (proj), 4 = the fp32 GEMMs of Vocos / EnCodec
+  if (c->prof_on) c->prof[cls].bytes += 2.0 * (double)M * N * K;      // flops for this class
   launch_gemm_f32(g, c->stream);
 }
 
@@ -252,7 +256,7 @@ void proj(vx_ctx* c, const float* A, int lda, const float* Wf, const unsigned sh
           const float* resid, int ldr, float* C, int ldc, long M, int N, int K, int act, const int* gather = nullptr,
           const unsigned short* a_pre = nullptr, unsigned short* out_pl = nullptr) {
   if (c->gemm_mode == 2 || !W3) {
-    gemm(c, A, lda, Wf, K, bias, resid, ldr, nullptr, C, ldc, M, N, K, act, gather);
+    gemm(c, A, lda, Wf, K, bias, resid, ldr, nullptr, C, ldc, M, N, K, act, gather, 2);
     return;
   }
   const long a_plane = c->gemm_mode == 0 ? h2_plane(M, K, H2_TILE_A) : (long)M * K;
@@ -313,18 +317,40 @@ int full_layer(vx_ctx* c, const LayerW& L, long M, const int* seq_off, const int
   return VX_OK;
 }
 
-// f16x2 operands must fit fp16: the split kernels raise a device flag instead of producing inf heads silently
-int check_range_flag(vx_ctx* c, const char* where) {
-  if (c->gemm_mode != 0 && !(c->attn_x3 && c->attn_h2)) return VX_OK;
+// ---- f16x2 range guard ---------------------------------------------------------------------------------------------
+// The f16x2 kernels need every scaled operand to fit fp16: |LayerNorm / attention / ReLU'd FFN activation| < 2047, |q|/8, |k|,
+// |v| < 2047 (vx_common.h).  The reference puts no bound on any of them (fp32 throughout: modules/transformer.py:371-373,
+// modules/activation.py:144-166), and trained transformers are known for massive activations.  The producers of the operand
+// planes raise `range_flag`; it is read at a host sync the phase has anyway (no extra round trip in the common case) and a
+// raised flag RE-RUNS THE PHASE on the exact-fp32 kernels (gemm_f32 / attn_full: the reference's own arithmetic, fp32 weights
+// are resident, the two extra activation buffers are allocated on first use) -- the call never fails and never returns
+// non-finite garbage because of the reduced-operand format.  vx_last_fallbacks() reports how often that happened.
+bool range_guarded(const vx_ctx* c) { return c->gemm_mode == 0 || (c->attn_x3 && c->attn_h2); }
+
+struct F32Scope {            // the full-sequence path on the exact-fp32 kernels for the lifetime of the object
+  vx_ctx* c;
+  int gm;
+  bool ax;
+  explicit F32Scope(vx_ctx* c_) : c(c_), gm(c_->gemm_mode), ax(c_->attn_x3) { c->gemm_mode = 2; c->attn_x3 = false; }
+  ~F32Scope() { c->gemm_mode = gm; c->attn_x3 = ax; }
+};
+
+int ensure_f32_buffers(vx_ctx* c) {
+  const long M = c->Mmax + 128;
+  if (!c->fatt) if (int e = dev_alloc(c, &c->fatt, (size_t)M * D_MODEL)) return e;
+  if (!c->fffn) if (int e = dev_alloc(c, &c->fffn, (size_t)M * D_FF)) return e;
+  return VX_OK;
+}
+
+// synchronous read-and-clear (paths without a sync of their own: vx_finalize_weights, the vx_ar_prefill test seam)
+int take_range_flag(vx_ctx* c, bool* raised) {
+  *raised = false;
+  if (!range_guarded(c)) return VX_OK;
   int flag = 0;
   HIPCHK(hipMemcpyAsync(&flag, c->range_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  if (flag) {
-    HIPCHK(hipMemsetAsync(c->range_flag, 0, sizeof(int), c->stream));
-    FAIL(VX_EHIP, "%s: an operand of a projection or of the attention is outside the range of the f16x2 format (|activation|, "
-                  "|q|/8, |k| or |v| >= 2047, or non-finite); rerun with VX_GEMM_X3=1 VX_ATTN_X3=1 (bf16x3) or VX_GEMM_F32=1 "
-                  "VX_ATTN_F32=1", where);
-  }
+  if (flag) HIPCHK(hipMemsetAsync(c->range_flag, 0, sizeof(int), c->stream));
+  *raised = flag != 0;
   return VX_OK;
 }
 
@@ -475,7 +501,7 @@ SampleArgs make_sample_args(vx_ctx* c, const vx_sampling* s, int commit, float* 
   a.temperature = s ? s->temperature : 1.0f;
   a.uniforms = (s && s->uniforms) ? c->d_uniforms : nullptr;
   a.uniforms_stride = c->cur_batch;
-  a.seed = s ? s->seed : 0;
+  a.seed_dev = c->seed_dev;
   a.force_eos_at = s ? s->force_eos_at : -1;
   a.commit = commit;
   a.cur_tok = c->cur_tok; a.cur_pos = c->cur_pos; a.ctx_len = c->ctx_len; a.n_gen = c->n_gen; a.active = c->active;
@@ -549,7 +575,8 @@ int ar_step_run(vx_ctx* c, const SampleArgs* sa, const std::string& sig) {
 // ---- AR generation for one micro-batch -----------------------------------------------------------------------
 int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int nb, std::vector<int>& n_gen,
                 std::vector<int>& gen, int beams = 1) {
-  if (int e = ar_prefill(c, b, r0, nb, beams)) return e;
+  const int nb_rows = nb;                            // rows of the caller's batch that this micro-batch prefills
+  if (int e = ar_prefill(c, b, r0, nb_rows, beams)) return e;
   const int ub = beams > 1 ? beams : b->batch;       // columns of the caller's uniforms: [steps][batch] or [steps][best_of]
   if (beams > 1) nb = beams;
   if (s->uniforms) {
@@ -563,22 +590,46 @@ int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int 
     HIPCHK(hipMemcpyAsync(c->d_uniforms, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
   }
-  HIPCHK(hipMemsetAsync(c->sum_logp, 0, MB * sizeof(float), c->stream));
+  // the seed of the counter-based sampler lives in a device word: a new seed per call (the reference's contract, every call
+  // draws from torch's generator) does not change the captured step graph
+  const unsigned long long seed = s->seed;
+  HIPCHK(hipMemcpyAsync(c->seed_dev, &seed, sizeof seed, hipMemcpyHostToDevice, c->stream));
   SampleArgs sa = make_sample_args(c, s, 1, nullptr);
-  launch_dec_sample(sa, c->stream);                                     // first token from the prefill logits
-  char sig[160];
-  snprintf(sig, sizeof sig, "b%d ns%d k%d t%a u%d f%d s%llu l%d", nb, c->nsplit, sa.top_k, sa.temperature,
-           sa.uniforms != nullptr, sa.force_eos_at, (unsigned long long)sa.seed, sa.sum_logp != nullptr);
-  const int sync_every = s->sync_every > 0 ? s->sync_every : 8;
   std::vector<int> act(nb);
+  bool any = true, raised = false;
+  // first token from the prefill logits; the host sync that tells whether anything is still active also brings the range
+  // flag of the prefill back (f16x2 guard, see F32Scope)
+  auto first_sample = [&]() -> int {
+    int flag = 0;
+    HIPCHK(hipMemsetAsync(c->sum_logp, 0, MB * sizeof(float), c->stream));
+    launch_dec_sample(sa, c->stream);
+    HIPCHK(hipMemcpyAsync(act.data(), c->active, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (range_guarded(c)) HIPCHK(hipMemcpyAsync(&flag, c->range_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    raised = flag != 0;
+    any = std::any_of(act.begin(), act.end(), [](int v) { return v != 0; });
+    return VX_OK;
+  };
+  if (int e = first_sample()) return e;
+  if (raised) {
+    // an operand of the prefill left the fp16 range: the K/V cache, the residual row and the logits are not to be trusted.
+    // Re-run the prefill on the exact-fp32 kernels (it resets the decode state) and sample the first token again.
+    HIPCHK(hipMemsetAsync(c->range_flag, 0, sizeof(int), c->stream));
+    ++c->st_fb_prefill; ++c->fb_total;
+    if (int e = ensure_f32_buffers(c)) return e;
+    {
+      F32Scope f32(c);
+      if (int e = ar_prefill(c, b, r0, nb_rows, beams)) return e;
+      if (int e = first_sample()) return e;
+    }
+  }
+  char sig[160];
+  snprintf(sig, sizeof sig, "b%d ns%d k%d t%a u%d f%d l%d", nb, c->nsplit, sa.top_k, sa.temperature,
+           sa.uniforms != nullptr, sa.force_eos_at, sa.sum_logp != nullptr);
+  const int sync_every = s->sync_every > 0 ? s->sync_every : 8;
   // with a forced EOS every row is inactive after force_eos_at steps: do not run on to the next host poll
   const int hard_cap = s->force_eos_at >= 0 ? std::min(c->gen_stride + 2, s->force_eos_at) : c->gen_stride + 2;
   int steps = 0;
-  bool any = true;
-  // was anything left active after the first sample?
-  HIPCHK(hipMemcpyAsync(act.data(), c->active, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  any = std::any_of(act.begin(), act.end(), [](int v) { return v != 0; });
   while (any && steps < hard_cap) {
     if (int e = ar_step_run(c, &sa, sig)) return e;
     ++steps;
@@ -593,7 +644,6 @@ int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int 
   HIPCHK(hipMemcpyAsync(n_gen.data(), c->n_gen, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(gen.data(), c->gen, gen.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  if (int e = check_range_flag(c, "AR prefill")) return e;
   c->st_steps += steps;
   if (c->prof_on) {
     // algorithmic KV bytes: every decode step of an active row reads ctx rows of K and V in all layers
@@ -606,8 +656,9 @@ int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int 
 }
 
 // ---- NAR: 7 stages (models/vallex.py:600-686, prefix_mode 1) ----------------------------------------------------
-int nar_generate(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::vector<int>& T, const int* codes0,
-                 long codes0_stride, std::vector<int>& out_codes /* [7][sumT] */, long& sumT_out) {
+constexpr int VX_RETRY_F32 = 1;      // internal: the phase raised the f16x2 range flag, run it again on the fp32 kernels
+int nar_generate_once(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::vector<int>& T, const int* codes0,
+                      long codes0_stride, std::vector<int>& out_codes /* [7][sumT] */, long& sumT_out) {
   const int NL = c->NL;
   std::vector<int> seq_off(nb), seq_len(nb), dst_t, id_t, lang_t, pos_t, ycodes, ynj, ydst, ypos, gen_rows, gen_y;
   long M = 0, Y = 0, sumT = 0;
@@ -692,8 +743,25 @@ int nar_generate(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::vector
   }
   HIPCHK(hipMemcpyAsync(out_codes.data(), c->imeta + o_samples, out_codes.size() * sizeof(int), hipMemcpyDeviceToHost,
                         c->stream));
+  int flag = 0;                        // the range flag rides on the sync that brings the ids back
+  if (range_guarded(c)) HIPCHK(hipMemcpyAsync(&flag, c->range_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  return check_range_flag(c, "NAR stages");
+  if (flag) {
+    HIPCHK(hipMemsetAsync(c->range_flag, 0, sizeof(int), c->stream));
+    return VX_RETRY_F32;
+  }
+  return VX_OK;
+}
+
+int nar_generate(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::vector<int>& T, const int* codes0,
+                 long codes0_stride, std::vector<int>& out_codes /* [7][sumT] */, long& sumT_out) {
+  int e = nar_generate_once(c, b, r0, nb, T, codes0, codes0_stride, out_codes, sumT_out);
+  if (e != VX_RETRY_F32) return e;
+  // an operand of one of the 7 stages left the fp16 range: the whole phase again on the exact-fp32 kernels (F32Scope)
+  ++c->st_fb_nar; ++c->fb_total;
+  if ((e = ensure_f32_buffers(c))) return e;
+  F32Scope f32(c);
+  return nar_generate_once(c, b, r0, nb, T, codes0, codes0_stride, out_codes, sumT_out);
 }
 
 int need(vx_ctx* c, const std::string& name, std::initializer_list<int64_t> shape) {
@@ -885,10 +953,16 @@ int vx_finalize_weights(vx_ctx* c) {
   const long M = c->Mmax + 128;
   if ((e = dev_alloc(c, &c->fx, (size_t)M * d))) return e;
   // kernel selection (read once per context): the defaults are the measured best
+  if (c->cfg.arith == VX_ARITH_F16X2) { c->gemm_mode = 0; c->attn_x3 = true; c->attn_h2 = true; }
+  else if (c->cfg.arith == VX_ARITH_BF16X3) { c->gemm_mode = 1; c->attn_x3 = true; c->attn_h2 = false; }
+  else if (c->cfg.arith == VX_ARITH_F32) { c->gemm_mode = 2; c->attn_x3 = false; }
+  else if (c->cfg.arith != VX_ARITH_DEFAULT) FAIL(VX_EINVAL, "vx_config.arith must be 0..3");
+  if (c->cfg.arith == VX_ARITH_DEFAULT) {      // the environment only speaks when the caller did not choose
   if (const char* ev = getenv("VX_GEMM_X3")) if (ev[0] == '1') c->gemm_mode = 1;
   if (const char* ev = getenv("VX_GEMM_F32")) if (ev[0] == '1') c->gemm_mode = 2;
   if (const char* ev = getenv("VX_ATTN_F32")) c->attn_x3 = !(ev[0] == '1');
   if (const char* ev = getenv("VX_ATTN_X3")) c->attn_h2 = !(ev[0] == '1');
+  }
   if ((e = dev_alloc(c, &c->fxn, (size_t)M * d))) return e;
   if ((e = dev_alloc(c, &c->fqkv, (size_t)M * 3 * d))) return e;
   // in f16x2 mode the attention output and the FFN hidden activations only ever exist as operand planes (fa3 / fa3b)
@@ -947,6 +1021,7 @@ int vx_finalize_weights(vx_ctx* c) {
 
   // ---- 16-bit operand planes of every transformer projection used on the full-sequence paths ----
   if ((e = dev_alloc(c, &c->range_flag, 1))) return e;
+  if ((e = dev_alloc(c, &c->seed_dev, 1))) return e;
   if (c->gemm_mode != 2) {
     const int P = c->gemm_mode == 0 ? 2 : 3;
     unsigned* d_max = nullptr;
@@ -1315,7 +1390,11 @@ int vx_finalize_weights(vx_ctx* c) {
   }
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipGetLastError());
-  if ((e = check_range_flag(c, "vx_finalize_weights"))) return e;
+  {
+    bool raised = false;          // weights are scaled from their own maximum: only a non-finite weight can raise the flag here
+    if ((e = take_range_flag(c, &raised))) return e;
+    if (raised) FAIL(VX_EINVAL, "vx_finalize_weights: a projection weight is not finite (NaN / inf in the state-dict)");
+  }
   c->finalized = true;
   return VX_OK;
 }
@@ -1324,8 +1403,17 @@ int vx_ar_prefill(vx_ctx* c, const vx_batch* b) {
   if (!c) return VX_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
   if (int e = check_batch(c, b, c->mbr)) return e;
+  c->st_fb_prefill = c->st_fb_nar = 0;
   if (int e = ar_prefill(c, b, 0, b->batch)) return e;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  bool raised = false;
+  if (int e = take_range_flag(c, &raised)) return e;       // syncs
+  if (raised) {
+    ++c->st_fb_prefill; ++c->fb_total;
+    if (int e = ensure_f32_buffers(c)) return e;
+    F32Scope f32(c);
+    if (int e = ar_prefill(c, b, 0, b->batch)) return e;
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
   HIPCHK(hipGetLastError());
   return VX_OK;
 }
@@ -1369,6 +1457,7 @@ int vx_nar(vx_ctx* c, const vx_batch* b, const int32_t* codes0, int32_t codes0_s
   }
   std::vector<int> oc;
   long sumT = 0;
+  c->st_fb_prefill = c->st_fb_nar = 0;
   if (int e = nar_generate(c, b, 0, b->batch, T, codes0, codes0_stride, oc, sumT)) return e;
   long off = 0;
   for (int i = 0; i < b->batch; ++i) {
@@ -1391,6 +1480,7 @@ int vx_infer(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int64_t* out_co
   if (int e = check_batch(c, b, c->cfg.max_batch)) return e;
   if (!(s->temperature > 0.f)) FAIL(VX_EINVAL, "temperature must be > 0");
   c->st_steps = 0; c->st_frames = 0; c->st_ar_ms = 0; c->st_nar_ms = 0; c->st_truncated = 0;
+  c->st_fb_prefill = c->st_fb_nar = 0;
   // a row that fills the arena although neither EOS, the reference's 16*S cap nor a forced EOS ended it was cut short
   auto cut_by_arena = [&](int n, int S) {
     return n >= c->gen_stride && c->gen_stride < 16 * S && !(s->force_eos_at >= 0 && s->force_eos_at <= c->gen_stride);
@@ -1773,7 +1863,7 @@ int vx_prof_reset(vx_ctx* c) {
 }
 
 int vx_prof_get(vx_ctx* c, int32_t which, double* total_ms, int64_t* launches, double* algo_bytes) {
-  if (!c || which < 0 || which > 3) return VX_EINVAL;
+  if (!c || which < 0 || which > 4) return VX_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
   HIPCHK(hipStreamSynchronize(c->stream));
   ProfClass& p = c->prof[which];
@@ -2093,6 +2183,22 @@ int vx_bench_attn(vx_ctx* c, int32_t batch, int32_t len, int32_t causal, int32_t
 #undef TRY
   cleanup();
   HIPCHK(hipGetLastError());
+  return VX_OK;
+}
+
+int vx_last_fallbacks(vx_ctx* c, int32_t* prefill_phases, int32_t* nar_phases, int64_t* lifetime) {
+  if (!c) return VX_EINVAL;
+  if (prefill_phases) *prefill_phases = c->st_fb_prefill;
+  if (nar_phases) *nar_phases = c->st_fb_nar;
+  if (lifetime) *lifetime = c->fb_total;
+  return VX_OK;
+}
+
+int vx_arith_mode(vx_ctx* c, int32_t* gemm_mode, int32_t* attn_mode) {
+  if (!c) return VX_EINVAL;
+  if (!c->finalized) FAIL(VX_ESTATE, "weights not finalized");
+  if (gemm_mode) *gemm_mode = c->gemm_mode;
+  if (attn_mode) *attn_mode = !c->attn_x3 ? 2 : (c->attn_h2 ? 0 : 1);
   return VX_OK;
 }
 

@@ -164,7 +164,7 @@ struct SampleArgs {
   const float* partial; int splitk; int npad;     // logits partials [splitk][MB][npad]
   int top_k; float temperature;
   const float* uniforms; int uniforms_stride;     // [steps][batch] or null
-  unsigned long long seed;
+  const unsigned long long* seed_dev;             // device word (not a launch constant: a new seed must not re-capture the graph)
   int force_eos_at;
   int commit;                                      // 0: only reduce (and export) the logits
   int* cur_tok; int* cur_pos; int* ctx_len; int* n_gen; int* active; int* n_active; const int* text_len;

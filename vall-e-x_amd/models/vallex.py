@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Sequence, Union
 import numpy as np
 
 from .. import macros
-from .._capi import Batch, Engine
+from .._capi import ARITH, Batch, Engine
 
 try:  # torch is plumbing only: the reference API hands tensors in and out
     import torch
@@ -127,7 +127,8 @@ class VALLE:
                                 max_new=int(kwargs.get("engine_max_new", 2048)),
                                 use_graph=bool(kwargs.get("engine_use_graph", True)),
                                 debug_taps=bool(kwargs.get("engine_debug_taps", False)),
-                                cu_mask=int(kwargs.get("engine_cu_mask", 0)))
+                                cu_mask=int(kwargs.get("engine_cu_mask", 0)),
+                                arith=kwargs.get("engine_arith", "default"))
 
     # ---- nn.Module-ish surface used by the reference's callers --------------------------------------------------
     def to(self, device):
@@ -182,7 +183,7 @@ class VALLE:
             o = self.engine_opts
             eng = Engine(self._device_id, self.num_layers, o["max_batch"], o["max_text"], o["max_prompt"], o["max_new"],
                          o["use_graph"], self._vocos_sd is not None, o["debug_taps"], self._encodec_sd is not None,
-                         o["cu_mask"])
+                         o["cu_mask"], ARITH[o["arith"]] if isinstance(o["arith"], str) else int(o["arith"]))
             for k, v in self._sd.items():
                 eng.load_tensor(k, v)
             tmax = o["max_text"] + o["max_prompt"] + o["max_new"] + 16
