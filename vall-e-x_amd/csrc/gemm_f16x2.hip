@@ -231,12 +231,12 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
 #pragma unroll
     for (int j = 0; j < HNDMA; ++j) *reinterpret_cast<f16x8*>(stage + lds_off[j] + lane * 16) = rg[j];
   };
-  f16x8 w0[2][NJ], a0[2][2], w1[2][TN == 128 ? NJ : 1], a1[2][2];
+  f16x8 w0[2][NJ], a0[2][2], w1[2][(TN == 128 || V == 16) ? NJ : 1], a1[2][2];
   // probes 14 / 15: one k16 step (fragments + its 24 MFMAs) with the next stage's DMA instructions threaded between the MFMAs:
   // 14: instruction j behind MFMA j + 1 of step 0 (j = 0..7); 15: instruction 4 s + 0..3 behind MFMAs 3, 9, 15, 21 of step s
   auto kstep_spread = [&](const unsigned char* stage, unsigned char* other, int kt_next, bool more, int s, f16x8 (&w)[2][NJ],
-                          f16x8 (&a)[2][2]) {
-    frags(stage, s, w, a);
+                          f16x8 (&a)[2][2], bool read_frags = true) {
+    if (read_frags) frags(stage, s, w, a);
     int n = 0;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
         for (int jn = 0; jn < NJ; ++jn) {
           acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[wp][jn], a[i][ap], acc[i][jn], 0, 0, 0);
           ++n;
-          if (V == 14 ? (s == 0 && n <= HNDMA) : (n % 6 == 3)) {
+          if (V == 14 ? (s == 0 && n <= HNDMA) : (n % 6 == 3)) {      // 15 / 16: behind every sixth MFMA
             const int j = V == 14 ? n - 1 : (4 * s + n / 6) % HNDMA;
             __builtin_amdgcn_sched_barrier(0);
             if (more)
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
   };
   auto ktile = [&](const unsigned char* stage, unsigned char* other, int kt_next, bool more, bool first, int sb) {
     (void)sb;
-    if (V != 14 && V != 15 && more && ((V != 1 && V != 13) || kt_next < 2)) dma(other, kt_next);
+    if (V != 14 && V != 15 && V != 16 && more && ((V != 1 && V != 13) || kt_next < 2)) dma(other, kt_next);
     VX_GSTAMP(sb >= 0, sb + 2);
     if constexpr (TN == 128) {
       if (V != 3 || first) {
@@ -272,6 +272,11 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
     } else if constexpr (V == 14 || V == 15) {
       kstep_spread(stage, other, kt_next, more, 0, w0, a0);
       kstep_spread(stage, other, kt_next, more, 1, w0, a0);
+    } else if constexpr (V == 16) {                 // 15 + both k16 steps' fragments requested up front (96 fragment registers)
+      frags(stage, 0, w0, a0);
+      frags(stage, 1, w1, a1);
+      kstep_spread(stage, other, kt_next, more, 0, w0, a0, false);
+      kstep_spread(stage, other, kt_next, more, 1, w1, a1, false);
     } else {                                        // 48 fragment registers: one k16 step at a time
       frags(stage, 0, w0, a0);
       mfmas(w0, a0);
@@ -432,11 +437,18 @@ void launch_gemm_f16x2_probe(const GemmX3Args& g, int variant, hipStream_t s) {
   else if (variant == 11) hipLaunchKernelGGL((gemm_f16x2_kernel<11, 128>), grid, block, 0, s, g);
   else if (variant == 12) hipLaunchKernelGGL((gemm_f16x2_kernel<12, 128>), grid, block, 0, s, g);
   else if (variant == 13) hipLaunchKernelGGL((gemm_f16x2_kernel<13, 128>), grid, block, 0, s, g);
-  else if (variant == 14 || variant == 15) {                     // 256 x 256 tile kernels: their own grid; N must be a multiple of 256
+  else if (variant == 14 || variant == 15) {                       // 256 x 256 tile kernels: their own grid; N must be a multiple of 256
     const dim3 grid256(((g.M + HM - 1) / HM) * (g.N / 256));
     if (g.N % 256 != 0) return;
     if (variant == 14) hipLaunchKernelGGL((gemm_f16x2_kernel<14, 256>), grid256, block, 0, s, g);
     else hipLaunchKernelGGL((gemm_f16x2_kernel<15, 256>), grid256, block, 0, s, g);
+  }
+  else if (variant == 16 || variant == 17 || variant == 18) {    // 16: see the kernel; 17 / 18: probes 1 / 2 (no DMA / no MFMAs) on the 256 x 256 tile
+    const dim3 grid256(((g.M + HM - 1) / HM) * (g.N / 256));
+    if (g.N % 256 != 0) return;
+    if (variant == 16) hipLaunchKernelGGL((gemm_f16x2_kernel<16, 256>), grid256, block, 0, s, g);
+    else if (variant == 17) hipLaunchKernelGGL((gemm_f16x2_kernel<1, 256>), grid256, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_f16x2_kernel<2, 256>), grid256, block, 0, s, g);
   }
   else hipLaunchKernelGGL((gemm_f16x2_kernel<4, 128>), grid, block, 0, s, g);
 }
