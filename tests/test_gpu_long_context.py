@@ -117,12 +117,12 @@ def test_edge_fixtures_from_the_live_reference(name):
     c = EDGE_CASES[name]
     g = golden(name)
     row, _ = inputs_row(c)
-    m = case_model(c, max_new=64, max_prompt=400, max_text=64, max_batch=4)
+    m = case_model(c, max_new=64, max_prompt=400, max_text=128, max_batch=4)
     out = m.inference(row["text"][None], np.array([len(row["text"])]), row["prompt"][None], row["enroll"], top_k=c["top_k"],
                       prompt_language=row["prompt_language"], text_language=row["text_language"], force_eos_at=c["force_eos_at"])
     assert tuple(out.shape) == g["codes"].shape, (name, tuple(out.shape), g["codes"].shape)
     np.testing.assert_array_equal(out.numpy(), g["codes"])
     if g["codes"].shape[1]:
-        m2 = case_model(c, debug_taps=True, max_new=64, max_prompt=400, max_text=64, max_batch=4)
+        m2 = case_model(c, debug_taps=True, max_new=64, max_prompt=400, max_text=128, max_batch=4)
         m2.engine.ar_prefill(m2.make_batch([row]))
         np.testing.assert_allclose(m2.engine.ar_logits()[0], g["ar_logits"][0], atol=3e-4, rtol=0)

@@ -347,6 +347,237 @@ void launch_dec_reduce_ln_pack(const float* partial, int splitk, int npad, const
 #undef VX_RLP
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Small batches (<= SB_MAX rows; BASELINE config 2 is ONE utterance): the step is a pure chain of launch latencies, so the tiny
+// kernels between the weight-streaming GEMMs are folded into the GEMM that consumes their output.  EVERY workgroup of the
+// consumer recomputes the few rows it needs (a row is 4 KB; SK + 1 slabs of it per row come out of L2) while its first weight
+// tile is already in flight:
+//   * reduce + residual + LayerNorm (dec_reduce_ln_pack)  -> prologue of the QKV / linear1 / predict GEMM,
+//   * the context-split combine of dec_attn (dec_attn_combine) -> prologue of the out_proj GEMM.
+// The arithmetic of a row is the code of the stand-alone kernels, operation for operation, so a row's ids do not depend on the
+// batch size it ran in.  The residual stream h ping-pongs between two buffers (workgroup 0 writes the new h while the others
+// still read the old one).  12 x 5 + 2 launches per step instead of 12 x 8 + 2.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int SB_MAX = SB_ROWS;
+constexpr float NEG_BIG = -1e30f;
+
+// one row by a team of 256 threads (thread tt owns float4 column tt); `red` = this team's [2][4] LDS words.  Contains two
+// __syncthreads(): every thread of the block must call it the same number of times (live = false: barriers only).
+template <int SK>
+__device__ __forceinline__ void sb_reduce_ln_row(bool live, const float* __restrict__ partial, int npad, const float* __restrict__ bias,
+                                                 const float* __restrict__ resid, float* __restrict__ h_out,
+                                                 const float* __restrict__ g, const float* __restrict__ bb, int m, int tt,
+                                                 float (*red)[4], float* __restrict__ xs_row) {
+  const int wid = tt >> 6, c = tt * 4;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f}, gg = v, be = v;
+  if (live) {
+    f32x4 p[SK];
+#pragma unroll
+    for (int ks = 0; ks < SK; ++ks) p[ks] = *reinterpret_cast<const f32x4*>(partial + ((long)ks * MB + m) * npad + c);
+    gg = *reinterpret_cast<const f32x4*>(g + c);
+    be = *reinterpret_cast<const f32x4*>(bb + c);
+    const f32x4 r = *reinterpret_cast<const f32x4*>(resid + (long)m * D_MODEL + c);
+    f32x4 bi = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bi = *reinterpret_cast<const f32x4*>(bias + c);
+    v = p[0];
+#pragma unroll
+    for (int ks = 1; ks < SK; ++ks)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += p[ks][e];
+    if (bias)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += bi[e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = r[e] + v[e];
+    if (h_out) *reinterpret_cast<f32x4*>(h_out + (long)m * D_MODEL + c) = v;
+  }
+  const float s1 = wave_sum64((v[0] + v[1]) + (v[2] + v[3]));
+  if ((tt & 63) == 0) red[0][wid] = s1;
+  __syncthreads();
+  const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * (1.0f / D_MODEL);
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q += d * d; }
+  q = wave_sum64(q);
+  if ((tt & 63) == 0) red[1][wid] = q;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * (1.0f / D_MODEL) + LN_EPS);
+  if (live) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * gg[e] + be[e];
+    *reinterpret_cast<f32x4*>(xs_row + c) = o;
+  }
+}
+
+// attention output of row m from the context-split partials: the body of dec_attn_combine_kernel (thread tt -> head tt >> 4,
+// float4 chunk tt & 15; splits in ascending order, ot / lt per element)
+__device__ __forceinline__ void sb_combine_row(const float* __restrict__ part_o, const float* __restrict__ part_ml, int nsplit, int m,
+                                               int tt, float* __restrict__ xs_row) {
+  const int h = tt >> 4, c = tt & 15;
+  const long pi = (long)(m * N_HEAD + h) * nsplit;
+  float mt = NEG_BIG;
+  for (int s = 0; s < nsplit; ++s) mt = fmaxf(mt, part_ml[(pi + s) * 2]);
+  float lt = 0.f;
+  f32x4 ot = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < nsplit; ++s) {
+    const float a = expf(part_ml[(pi + s) * 2] - mt);
+    lt += part_ml[(pi + s) * 2 + 1] * a;
+    const f32x4 o = *reinterpret_cast<const f32x4*>(part_o + (pi + s) * D_HEAD + c * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ot[e] += o[e] * a;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) ot[e] = ot[e] / lt;
+  *reinterpret_cast<f32x4*>(xs_row + h * D_HEAD + c * 4) = ot;
+}
+
+// skinny_gemm_kernel (K = 1024) whose x operand is computed by the prologue.  MODE 0: rows = LN(resid + sum of SK slabs + bias);
+// MODE 1: rows = combine of the dec_attn partials (SK unused).  The first weight tile is requested BEFORE the prologue.
+template <int MODE, int SK>
+__global__ __launch_bounds__(256) void skinny_gemm_sb_kernel(const float* __restrict__ Wp, float* __restrict__ out, int Npad, int splitk,
+                                                             const float* __restrict__ partial, int pnpad, const float* __restrict__ bias,
+                                                             const float* __restrict__ resid, float* __restrict__ h_out,
+                                                             const float* __restrict__ g, const float* __restrict__ bb,
+                                                             const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                             int nsplit, int M) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  __shared__ __attribute__((aligned(16))) float xs[SB_MAX][D_MODEL];
+  __shared__ float st[2][4];
+  constexpr int K = D_MODEL;
+  const int nt = blockIdx.x, ks = blockIdx.y;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  constexpr int KB = K / 8;
+  const int kb_per_wave = KB / (splitk * 4);
+  const int kb0 = (ks * 4 + wid) * kb_per_wave;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + ((long)nt * KB + kb0) * 64 + lane;
+  f32x4 w[8], x[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + (long)u * 64);
+  const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+  for (int m = 0; m < M; ++m) {
+    if (MODE == 0) sb_reduce_ln_row<SK>(true, partial, pnpad, bias, resid, first ? h_out : nullptr, g, bb, m, threadIdx.x, st, xs[m]);
+    else sb_combine_row(part_o, part_ml, nsplit, m, threadIdx.x, xs[m]);
+  }
+  __syncthreads();
+  // x fragment of lane (b = lane & 31, hi = lane >> 5) for k-block kb: x[b][8 kb + 4 hi ..]; rows >= M are zero columns of the MFMA
+  const int b = lane & 31, hi = lane >> 5;
+  const float* xrow = xs[b < M ? b : 0] + 4 * hi;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int i = 0;;) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = b < M ? *reinterpret_cast<const f32x4*>(xrow + (long)(kb0 + i + u) * 8) : zero;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[u][j], x[u][j], acc, 0, 0, 0);
+    i += 8;
+    if (i >= kb_per_wave) break;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + (long)(i + u) * 64);
+  }
+  // epilogue of skinny_gemm_kernel
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[((wid * 16 + r) * 64) + lane] = acc[r];
+  __syncthreads();
+  f32x4 t;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float* rp = red + ((wid * 4 + j) * 64) + lane;
+    t[j] = ((rp[0] + rp[16 * 64]) + rp[2 * 16 * 64]) + rp[3 * 16 * 64];
+  }
+  float* dst = out + ((long)ks * MB + (lane & 31)) * Npad + nt * 32 + 4 * (lane >> 5);
+  *reinterpret_cast<f32x4*>(dst + wid * 8) = t;
+}
+
+void launch_skinny_gemm_sb_ln(const float* Wp, float* partial_out, int Npad, int splitk, const float* partial_in, int sk_in,
+                              const float* bias, const float* resid, float* h_out, const float* g, const float* b, int batch,
+                              hipStream_t s) {
+  if (sk_in == 8)
+    hipLaunchKernelGGL((skinny_gemm_sb_kernel<0, 8>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, partial_in,
+                       D_MODEL, bias, resid, h_out, g, b, nullptr, nullptr, 0, batch);
+  else if (sk_in == 4)
+    hipLaunchKernelGGL((skinny_gemm_sb_kernel<0, 4>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, partial_in,
+                       D_MODEL, bias, resid, h_out, g, b, nullptr, nullptr, 0, batch);
+  else { fprintf(stderr, "launch_skinny_gemm_sb_ln: split-K factor %d of the producer is not compiled in\n", sk_in); abort(); }
+}
+
+void launch_skinny_gemm_sb_combine(const float* Wp, float* partial_out, int Npad, int splitk, const float* part_o, const float* part_ml,
+                                   int nsplit, int batch, hipStream_t s) {
+  hipLaunchKernelGGL((skinny_gemm_sb_kernel<1, 1>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, nullptr, 0,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, part_o, part_ml, nsplit, batch);
+}
+
+// skinny16_relu_pack_kernel (linear1) with the reduce + residual + LayerNorm of its input rows as prologue; rows 16..31 of the
+// MFMA column blocks do not exist at these batch sizes, so the second accumulator is dropped.
+template <int SK>
+__global__ __launch_bounds__(S16_WAVES * 64) void skinny16_sb_kernel(const float* __restrict__ W16, const float* __restrict__ bias,
+                                                                     float* __restrict__ xp_out, const float* __restrict__ partial,
+                                                                     const float* __restrict__ pbias, const float* __restrict__ resid,
+                                                                     float* __restrict__ h_out, const float* __restrict__ g,
+                                                                     const float* __restrict__ bb, int M) {
+  __shared__ __attribute__((aligned(16))) float red[S16_WAVES * 4 * 64];
+  __shared__ __attribute__((aligned(16))) float xs[SB_MAX][D_MODEL];
+  __shared__ float st[2][2][4];
+  constexpr int K = D_MODEL;
+  const int nt = blockIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  constexpr int KB = K / 16, per = KB / S16_WAVES;
+  const int kb0 = wid * per;
+  const int kg = lane >> 4, bl = lane & 15;
+  const f32x4* wp = reinterpret_cast<const f32x4*>(W16) + ((long)nt * KB + kb0) * 64 + lane;
+  f32x4 w[8], x0[8];
+  const f32x4 bi = *reinterpret_cast<const f32x4*>(bias + nt * 16 + 4 * kg);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + (long)u * 64);
+  // two teams of 256 threads: team 0 rows 0, 2; team 1 rows 1, 3
+  const int team = threadIdx.x >> 8, tt = threadIdx.x & 255;
+  const bool first = blockIdx.x == 0;
+  for (int r0 = 0; r0 < M; r0 += 2) {
+    const int m = r0 + team;
+    sb_reduce_ln_row<SK>(m < M, partial, D_MODEL, pbias, resid, first ? h_out : nullptr, g, bb, m < M ? m : 0, tt, st[team], xs[m < M ? m : 0]);
+  }
+  __syncthreads();
+  const float* xrow = xs[bl < M ? bl : 0] + 4 * kg;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
+  static_assert(per == 8, "one round of 8 k-blocks per wave at K = 1024");
+#pragma unroll
+  for (int u = 0; u < 8; ++u) x0[u] = bl < M ? *reinterpret_cast<const f32x4*>(xrow + (long)(kb0 + u) * 16) : zero;
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][j], x0[u][j], acc0, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[(wid * 4 + r) * 64 + lane] = acc0[r];
+  __syncthreads();
+  if (wid == 0) {
+    f32x4 a4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float sum = red[r * 64 + lane];
+#pragma unroll
+      for (int w2 = 1; w2 < S16_WAVES; ++w2) sum += red[(w2 * 4 + r) * 64 + lane];
+      a4[r] = sum;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a4[r] = fmaxf(a4[r] + bi[r], 0.f);
+    float* o = xp_out + (((long)(2 * nt + (kg >> 1)) * 64) + bl + 32 * (kg & 1)) * 4;
+    *reinterpret_cast<f32x4*>(o) = a4;
+  }
+}
+
+void launch_skinny16_sb_ln(const float* W16, const float* bias, float* xp_out, int N, const float* partial_in, int sk_in,
+                           const float* pbias, const float* resid, float* h_out, const float* g, const float* b, int batch,
+                           hipStream_t s) {
+  if (sk_in != 4) { fprintf(stderr, "launch_skinny16_sb_ln: split-K factor %d of the producer is not compiled in\n", sk_in); abort(); }
+  hipLaunchKernelGGL((skinny16_sb_kernel<4>), dim3(N / 16), dim3(S16_WAVES * 64), 0, s, W16, bias, xp_out, partial_in, pbias, resid, h_out,
+                     g, b, batch);
+}
+
 // Start of a step: embed the newest token of each row at its audio position (the reference re-embeds all of y and
 // keeps the last row, models/vallex.py:529-531,552-553), then norm1 of layer 0.
 __global__ __launch_bounds__(64) void dec_embed_ln_pack_kernel(const int* __restrict__ tok,
@@ -396,7 +627,6 @@ __device__ __forceinline__ float dpp_sum16(float x) {
   return x;
 }
 
-constexpr float NEG_BIG = -1e30f;
 constexpr int ATT_U = 4;              // rows per lane-group per buffer; two buffers in flight (2 x 8 KiB per wave)
 constexpr int ATT_WAVES = 8;          // 512-thread workgroup
 constexpr int ATT_STRIDE = ATT_WAVES * 4 * ATT_U;   // rows consumed per block iteration
@@ -883,6 +1113,9 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
   cand = wave_min64i(cand);
   const int last_all = wave_max64i(lastnz);
   int tok = cand == 0x7fffffff ? last_all : cand;
+  // non-finite logits (an f16x2 operand of the prefill left the fp16 range: the engine re-runs the prefill in fp32 and samples
+  // again) leave no candidate at all: keep the index inside the tables, the token of such a pass is never used
+  if ((unsigned)tok > (unsigned)EOS_ID) tok = EOS_ID;
 
   // log-prob of the pick under the filtered distribution (F.log_softmax, models/vallex.py:851-852), accumulated per
   // row for best-of-N beam selection (models/vallex.py:572); the owning lane adds it.

@@ -93,7 +93,8 @@ struct vx_ctx {
 
   // decode arena
   float *kc = nullptr, *vc = nullptr;      // [NL][mbr*16][Tmax][64]
-  float *dh = nullptr, *xp = nullptr, *xp_att = nullptr, *xp4 = nullptr;
+  float *dh = nullptr, *dh2 = nullptr, *xp = nullptr, *xp_att = nullptr, *xp4 = nullptr;
+  bool sb_fuse = true;             // <= SB_ROWS rows: reduce+LN / combine folded into the consuming GEMM (VX_SB_FUSE=0: the general chain)
   float *p_qkv = nullptr, *p_o = nullptr, *p_oh = nullptr, *p_logits = nullptr, *part_o = nullptr, *part_ml = nullptr;
   std::map<const unsigned short*, int> w_shift;   // f16x2: power-of-two scale exponent of every weight's planes
   bool balance_rows = true;        // dec_attn launch order pairs long with short contexts per CU (VX_BALANCE_ROWS=0: batch order)
@@ -526,6 +527,42 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
   if (!sa)
     launch_dec_embed_ln_pack(c->cur_tok, c->cur_pos, W(c, "ar_audio_embedding.word_embeddings.weight"),
                              W(c, "ar_audio_position.alpha"), c->pe, c->dh, c->ar[0].n1_w, c->ar[0].n1_b, c->xp, nb, st);
+  if (c->sb_fuse && nb <= SB_ROWS && c->nsplit > 1) {
+    // small batch (BASELINE config 2: one utterance): 5 launches per layer -- QKV | dec_attn partials | out_proj | linear1 | linear2 --
+    // every reduce + residual + LayerNorm and the context-split combine run in the prologue of the GEMM that consumes them
+    // (decode.hip: skinny_gemm_sb_kernel, skinny16_sb_kernel).  The residual stream alternates between dh and dh2.
+    float *hr = c->dh, *hw = c->dh2;            // the sampler / embed kernel left h in dh
+    for (int l = 0; l < NL; ++l) {
+      const LayerW& L = c->ar[l];
+      {
+        ProfScope ps(c, 1);
+        if (l == 0) launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, st);      // xp = norm1(h) from the sampler
+        else {
+          launch_skinny_gemm_sb_ln(L.in_wp, c->p_qkv, 3 * D_MODEL, SK_QKV, c->p_o, SK_L2, c->ar[l - 1].l2_b, hr, hw, L.n1_w, L.n1_b, nb, st);
+          std::swap(hr, hw);
+        }
+      }
+      {
+        ProfScope ps(c, 0);
+        launch_dec_attn(c->p_qkv, SK_QKV, L.in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax, c->slot_meta,
+                        c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, nullptr, c->p_oh, st);
+      }
+      { ProfScope ps(c, 1); launch_skinny_gemm_sb_combine(L.out_wp, c->p_o, D_MODEL, SK_OUT, c->part_o, c->part_ml, c->nsplit, nb, st); }
+      {
+        ProfScope ps(c, 1);
+        launch_skinny16_sb_ln(L.l1_wp, L.l1_b, c->xp4, D_FF, c->p_o, SK_OUT, L.out_b, hr, hw, L.n2_w, L.n2_b, nb, st);
+        std::swap(hr, hw);
+      }
+      { ProfScope ps(c, 1); launch_skinny_gemm(L.l2_wp, c->xp4, c->p_o, D_MODEL, D_FF, SK_L2, st); }
+    }
+    {
+      ProfScope ps(c, 1);
+      launch_skinny_gemm_sb_ln(c->pred_wp, c->p_logits, PRED_NPAD, SK_PRED, c->p_o, SK_L2, c->ar[NL - 1].l2_b, hr, nullptr,
+                               W(c, "ar_decoder.norm.weight"), W(c, "ar_decoder.norm.bias"), nb, st);
+    }
+    if (sa) launch_dec_sample(*sa, st);
+    return;
+  }
   for (int l = 0; l < NL; ++l) {
     const LayerW& L = c->ar[l];
     { ProfScope ps(c, 1); launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, st); }
@@ -976,6 +1013,8 @@ int vx_finalize_weights(vx_ctx* c) {
   if ((e = dev_alloc(c, &c->kc, cache, false))) return e;
   if ((e = dev_alloc(c, &c->vc, cache, false))) return e;
   if ((e = dev_alloc(c, &c->dh, (size_t)MB * d))) return e;
+  if ((e = dev_alloc(c, &c->dh2, (size_t)MB * d))) return e;
+  if (const char* ev = getenv("VX_SB_FUSE")) c->sb_fuse = !(ev[0] == '0');
   if ((e = dev_alloc(c, &c->xp, (size_t)MB * d))) return e;
   if ((e = dev_alloc(c, &c->xp_att, (size_t)MB * d))) return e;
   if ((e = dev_alloc(c, &c->xp4, (size_t)2 * MB * f))) return e;   // linear1's two split-K slabs, packed image

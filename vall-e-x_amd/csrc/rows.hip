@@ -233,7 +233,9 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
     const int oi = __shfl_xor(bi, o, 64);
     if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
   }
-  if (lane == 0) idx[row] = bi;
+  // a row without any comparable value (all NaN: an f16x2 operand left the fp16 range; the phase is re-run in fp32) must still
+  // yield a valid table index -- the ids of such a pass are thrown away, a wild gather would fault
+  if (lane == 0) idx[row] = bi == 0x7fffffff ? 0 : bi;
 }
 
 void launch_argmax_rows(const float* x, int ldx, int rows, int N, int* idx, hipStream_t s) {

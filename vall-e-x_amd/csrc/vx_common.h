@@ -147,6 +147,19 @@ void launch_dec_reduce_ln_pack(const float* partial, int splitk, int npad, const
 void launch_pack_weight16(const float* W, int N, int K, float* Wp, hipStream_t s);
 void launch_skinny16_relu_pack(const float* W16, const float* xp, const float* bias, float* xp_out, int N, int K,
                                hipStream_t s);
+// small batches (<= SB_ROWS rows): the consumer GEMM computes its own input rows in its prologue (decode.hip)
+constexpr int SB_ROWS = 4;
+// partial_out[ks][b][n] = sum_k LN(resid[b] + sum_ks' partial_in[ks'][b] + bias)[k] W[n][k]   (K = 1024); workgroup 0 writes h_out
+void launch_skinny_gemm_sb_ln(const float* Wp, float* partial_out, int Npad, int splitk, const float* partial_in, int sk_in,
+                              const float* bias, const float* resid, float* h_out, const float* g, const float* b, int batch,
+                              hipStream_t s);
+// the same GEMM on the combine of dec_attn's context-split partials (out_proj, K = 1024)
+void launch_skinny_gemm_sb_combine(const float* Wp, float* partial_out, int Npad, int splitk, const float* part_o, const float* part_ml,
+                                   int nsplit, int batch, hipStream_t s);
+// linear1 (bias + ReLU + pack fused, 16-row tiles) on LN(resid + sum of the out_proj slabs + pbias)
+void launch_skinny16_sb_ln(const float* W16, const float* bias, float* xp_out, int N, const float* partial_in, int sk_in,
+                           const float* pbias, const float* resid, float* h_out, const float* g, const float* b, int batch,
+                           hipStream_t s);
 // h[b] = tab[tok[b]] + alpha*pe[pos[b]] ; xp = pack(LN(h))  -- start of a decode step
 void launch_dec_embed_ln_pack(const int* tok, const int* pos, const float* tab, const float* alpha, const float* pe,
                               float* h, const float* g, const float* b, float* xp, int batch, hipStream_t s);
