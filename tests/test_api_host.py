@@ -207,3 +207,22 @@ def test_vocos_state_dict_keeps_only_the_head_tensors():
     bad.pop("head.out.bias")
     with pytest.raises(RuntimeError, match="missing"):
         _valle(2).load_vocos_state_dict(bad)
+
+
+def test_make_transcript_normalises_a_clipping_waveform_in_place():
+    """utils/prompt_making.py:91-92: `if wav.abs().max() > 1: wav /= wav.abs().max()` mutates the tensor make_prompt goes on to
+    tokenize -- the mirror must hand the SAME (normalised) samples to the EnCodec encoder."""
+    import numpy as np
+    from vallex_amd.utils import generation as G
+    from vallex_amd.utils import prompt_making as PM
+    G.language_detector = lambda text: "en"
+    try:
+        wav = np.array([[0.5, -3.0, 1.5, 0.0]], np.float32)
+        text, lang = PM.make_transcript("x", wav, 24000, "hello")
+        assert (text, lang) == ("[EN]hello[EN]", "en")
+        np.testing.assert_array_equal(wav, np.array([[0.5, -3.0, 1.5, 0.0]], np.float32) / np.float32(3.0))
+        quiet = np.array([[0.5, -0.9]], np.float32)
+        PM.make_transcript("x", quiet, 24000, "hello")
+        np.testing.assert_array_equal(quiet, np.array([[0.5, -0.9]], np.float32))          # peaks <= 1 stay untouched
+    finally:
+        G.language_detector = None

@@ -116,7 +116,7 @@ def test_canonical_state_dict_covers_the_encoder():
         np.testing.assert_allclose(canon[k], want[k], atol=1e-6, rtol=1e-6)
 
 
-def _codes_agree_up_to_ties(got, gold, emb, dec_sd, tol=1e-3):
+def _codes_agree_up_to_ties(got, gold, emb, dec_sd, tol=1e-4):
     """RVQ codes can legitimately differ from another fp32 implementation where two codewords are (nearly) equidistant
     (the GEMM summation order decides).  Accept a frame if its codes are equal, or if at the FIRST differing codebook both
     candidates are within `tol` (relative) of the minimum distance in float64; later codebooks of that frame then differ
@@ -156,7 +156,10 @@ def test_hip_encoder_matches_transformers_port():
         assert got.shape == gold.shape
         emb = orc.embeddings(wav).numpy()
         ties = sum(_codes_agree_up_to_ties(got[b], gold[b], emb[b], dec) for b in range(got.shape[0]))
-        assert ties <= max(1, gold.shape[0] * gold.shape[1] // 10), ties  # a few near-ties at most
+        frames = gold.shape[0] * gold.shape[1]
+        print(f"{name}: {frames - ties} of {frames} frames bit-identical on all 8 codebooks, {ties} decided by a near-tie "
+              f"(both candidates within 1e-4 relative of the float64 minimum distance)")
+        assert ties <= max(1, frames // 50), ties                         # near-ties: at most 2 % of the frames
 
 
 @pytest.mark.gpu

@@ -62,8 +62,11 @@ def build_library(force: bool = False, verbose: bool = False, dev: bool = False)
     os.makedirs(out_dir, exist_ok=True)
     lib = os.path.join(out_dir, "libvallex_hip.so")
     flags = FLAGS + (["-DVX_DEV_PROBES"] if dev else [])
-    for s in SOURCES:
-        src = os.path.join(CSRC, s)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    if dev:      # the research template of the f16x2 GEMM with its timing probes: a tools-only translation unit
+        srcs.append(os.path.join(os.path.dirname(HERE), "tools", "dev_src", "gemm_f16x2_probes.hip"))
+    for src in srcs:
+        s = os.path.basename(src)
         obj = os.path.join(out_dir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs, flags):
@@ -84,7 +87,7 @@ def build_library(force: bool = False, verbose: bool = False, dev: bool = False)
     if force or jobs or _stale(lib, objs):
         run(([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, lib, objs))
         relinked = True
-    print(f"[build] {len(jobs)} of {len(SOURCES)} sources compiled for gfx950, library {'linked' if relinked else 'up to date (source AND object digests match)'}",
+    print(f"[build] {len(jobs)} of {len(srcs)} sources compiled for gfx950, library {'linked' if relinked else 'up to date (source AND object digests match)'}",
           flush=True)
     return lib
 

@@ -10,11 +10,17 @@
 // (profiles/r02_gemm_ab.log).  Every live-reference golden (short, sharp-attention, full-length 600 x 8 ids) stays bit-exact.
 // Speed: 270-320 fp32-equivalent TF vs 172-186 for bf16x3 on the same shapes (x 1.6-1.7).
 // fp16 range: |X| must stay below 65504, i.e. |activation| < 2047 (LayerNorm outputs, ReLU'd FFN activations, attention outputs
-// of this model are far inside; a device flag turns a violation into an error that names the fallbacks); weights are scaled
+// of this model are far inside; a device flag makes the engine re-run the phase in exact fp32 otherwise); weights are scaled
 // from their own max.  Tails below 2^-14 are fp16 subnormals (honoured by the matrix cores): <= 2^-25 * 2^-s absolute.
 //
-// Structure = gemm_bf16x3_dma.hip: tile 256 x 128 x 32, 8 waves (4 x 2), wave tile 64 x 64, global_load_lds_dwordx4 into two
-// LDS stages (2 planes x (256 + 128) rows x 64 B = 48 KiB each), XOR swizzle applied on the global side.
+// Structure: tile 256 x 256 x 32 for every N that is a multiple of 256 (all projections of the model; 8 waves 4 x 2, wave tile
+// 64 x 128 = 8 accumulator blocks, 128 accumulator registers, fragments read one k16 step at a time) and 256 x 128 x 32 otherwise
+// / for row sets too short to fill the chip with 256-wide tiles (wave tile 64 x 64).  Operand tiles go global -> LDS with
+// global_load_lds_dwordx4 (no VGPR round trip) into two LDS stages of 64 / 48 KiB (2 planes x (256 + TN) rows x 64 B), the XOR
+// swizzle of the 64-B LDS rows applied on the global side.  256-wide tile: the eight DMA instructions a wave issues for the NEXT
+// stage are threaded between the MFMAs of this K tile (one behind every sixth MFMA) instead of back to back behind the rendezvous
+// with the matrix pipe idle: -2 .. -7 % on the four NAR shapes (profiles/r03_gemm_bench.log, columns h2-256x256 vs -dma-spread),
+// same sums.  The timing probes this kernel grew up with live in tools/dev_src/gemm_f16x2_probes.hip (tools-only build).
 #include <algorithm>
 
 #include "vx_common.h"
@@ -39,8 +45,8 @@ typedef void __attribute__((address_space(3)))* lptr_t;
 // contiguous run (TR * K * 2 B per plane), walked linearly by its K loop -- instead of 16 KiB pieces 64 B * rows apart
 // (K-tile-major, the bf16x3 layout), i.e. one DRAM page / TLB entry per K tile and workgroup.  Rows past `rows` in the last
 // tile are never written (the GEMM reads them as garbage into accumulator rows it never stores).
-// range_flag (optional): set to 1 if any |x| does not fit fp16 (>= 65504 or non-finite) -- the engine turns that into an error
-// instead of letting an inf head poison the GEMM silently.
+// range_flag (optional): set to 1 if any |x| does not fit fp16 (>= 65504 or non-finite) -- the engine then re-runs the phase on
+// the exact-fp32 kernels instead of letting an inf head poison the GEMM silently.
 __global__ __launch_bounds__(256) void split2h_kernel(const float* __restrict__ x, int ldx, long rows, int K,
                                                       const int* __restrict__ gather,
                                                       unsigned short* __restrict__ planes, long plane_stride, int tile_rows,
@@ -94,45 +100,17 @@ void launch_absmax(const float* x, long n, unsigned* out_bits, hipStream_t s) {
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 2048)), dim3(256), 0, s, x, n, out_bits);
 }
 
-#ifdef VX_DEV_PROBES
-// development aid (tools/gemm_timeline.py): shader-clock stamps of wave 0 of the first 256 workgroups around two consecutive
-// k-steps in steady state: [0] before the rendezvous, [1] after it, [2] DMA of the next stage issued, [3] fragment reads issued,
-// [4] MFMAs issued, then the same five for the second k-step at [5..9]; [10] loop done, [11] epilogue done, [12] entry
-__device__ unsigned long long vx_gstamps[256 * 16];
-#define VX_GSTAMP(COND, SLOT)                                                                     \
-  do {                                                                                            \
-    if ((COND) && threadIdx.x == 0 && blockIdx.x < 256) vx_gstamps[blockIdx.x * 16 + (SLOT)] = __builtin_readcyclecounter(); \
-  } while (0)
-void dev_read_gemm_stamps(unsigned long long* out) {
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(vx_gstamps), sizeof(unsigned long long) * 256 * 16);
-}
-#else
-#define VX_GSTAMP(COND, SLOT)
-#endif
-
-// V = 0 product kernel.  Timing probes (VX_DEV_PROBES builds, tools/gemm_bench.py; results meaningless): V = 1 no DMA after the
-// first two tiles; V = 2 no MFMAs; V = 3 fragments read once; V = 4 no barriers / vmcnt waits (racy); V = 11 / 12 operands staged
-// through registers instead of LDS-DMA (12: without the MFMAs).
-// V = 13: probe 1 (no DMA) with ONE aliased LDS stage and two workgroups per CU -- does the compute path (fragment reads,
-// MFMAs, barriers) run faster when a second, independent workgroup shares the CU?
-// V = 14 / 15 (TN = 256 only; real kernels: same sums as V = 0): the eight LDS-DMA instructions of the next stage are not issued
-// back to back right behind the rendezvous -- by all eight waves of the CU at once, with the matrix pipe idle meanwhile -- but one
-// at a time between the MFMAs of this K tile (ISA of V = 0: barrier | 8 x [2 v_lshl_add_u64, s_mov m0, global_load_lds] | 6 ds_read |
-// 8 MFMA | 6 ds_read | 16 MFMA | 6 ds_read | 8 MFMA | 6 ds_read | 16 MFMA).  14: behind each of the FIRST eight MFMAs (the
-// data still has almost the whole K tile to land: with two stages the landing time is what the next rendezvous waits for);
-// 15: behind every sixth MFMA (even spread; the last requests are issued late).
-// TN = 256: a 256 x 256 tile (wave tile 64 x 128, 128 accumulator registers -- possible since the single accumulator): a third
-// less operand traffic per flop and half the barriers; its fragments are read one k16 step at a time (48 registers).
-template <int V, int TN>
-__global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3Args g) {
+template <int TN>
+__global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
   constexpr int HN = TN, HW_PL = TN * HLD, HSTAGE = 2 * HA_PL + 2 * HW_PL;     // 48 / 64 KiB per stage
   constexpr int HNDMA = HSTAGE / (8 * 1024);                                    // 1 KiB DMA instructions per wave and stage: 6 / 8
   constexpr int NJ = TN / 64;                                                   // 32-column blocks of a wave: 2 / 4
   __shared__ __attribute__((aligned(1024))) unsigned char stage0[HSTAGE];
-  __shared__ __attribute__((aligned(1024))) unsigned char stage1_[V == 13 ? 16 : HSTAGE];
-  unsigned char* const stage1 = V == 13 ? stage0 : stage1_;
+  __shared__ __attribute__((aligned(1024))) unsigned char stage1[HSTAGE];
 
-  constexpr int GM = V == 5 ? 4 : V == 6 ? 16 : V == 7 ? 2 : 8;     // probes 5-7: other XCD-wave shapes (GM x 32/GM tiles)
+  // XCD-aware order: consecutive block ids land on different XCDs (round robin), so XCD x walks its own contiguous range of
+  // tiles, in groups of GM row tiles x all column tiles (the A panels of a group stay in that XCD's L2 while W streams)
+  constexpr int GM = 8;
   const int tiles_m = (g.M + HM - 1) / HM, tiles_n = (g.N + HN - 1) / HN;
   const int nwg = tiles_m * tiles_n;
   int wg = blockIdx.x;
@@ -165,15 +143,17 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
     const int row = r16 * 16 + (lane >> 2) + (isA ? 0 : (tn * TN) % WTR);
     const int ch = (lane & 3) ^ ((lane >> 4) & 3);
     // tile-major planes: a panel is K/32 blocks of 256 rows x 32 (this workgroup's rows of each block are one contiguous run)
-    const long tile0 = (V == 8 || V == 9) ? 0 : (long)(isA ? tm : (tn * TN) / WTR) * (g.K / HK) * ((isA ? HM : WTR) * HK);   // probes 8/9: every workgroup streams tile 0 (all L2 hits)
+    const long tile0 = (long)(isA ? tm : (tn * TN) / WTR) * (g.K / HK) * ((isA ? HM : WTR) * HK);
     src[j] = (isA ? g.A + p * g.a_plane : g.W + p * g.w_plane) + tile0 + (long)row * HK + ch * 8;
     kstep[j] = (long)(isA ? HM : WTR) * HK;
     lds_off[j] = (isA ? p * HA_PL : 2 * HA_PL + p * HW_PL) + r16 * 1024;
   }
+  auto dma1 = [&](unsigned char* stage, int kt, int j) {
+    __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + kt * kstep[j]), (lptr_t)(stage + lds_off[j]), 16, 0, 0);
+  };
   auto dma = [&](unsigned char* stage, int kt) {
 #pragma unroll
-    for (int j = 0; j < (V == 10 ? 4 : HNDMA); ++j)            // probe 10: two thirds of the operand bytes (results meaningless)
-      __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + kt * kstep[j]), (lptr_t)(stage + lds_off[j]), 16, 0, 0);
+    for (int j = 0; j < HNDMA; ++j) dma1(stage, kt, j);
   };
 
   f32x16 acc[2][NJ];                                             // ONE accumulator per 32 x 32 block: tail and head products share a scale
@@ -198,137 +178,58 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
 #pragma unroll
       for (int p = 0; p < 2; ++p) a[i][p] = *reinterpret_cast<const f16x8*>(stage + p * HA_PL + a_row + i * 32 * HLD + coff);
   };
-  auto mfmas = [&](const f16x8 (&w)[2][NJ], const f16x8 (&a)[2][2]) {
-    // transposed product (A operand = W rows); the three terms of a block go into the same accumulator, small ones first; the
-    // four blocks of the wave take turns so that no MFMA waits for the one before it on the same accumulator
-    if (V == 2 || V == 9 || V == 12) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int jn = 0; jn < NJ; ++jn)
-          acc[i][jn][0] += (float)w[1][jn][0] * (float)a[i][0][0] + (float)w[0][jn][1] * (float)a[i][1][1] + (float)w[0][jn][0] * (float)a[i][0][0];
-      return;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jn = 0; jn < NJ; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[1][jn], a[i][0], acc[i][jn], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jn = 0; jn < NJ; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][jn], a[i][1], acc[i][jn], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jn = 0; jn < NJ; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[0][jn], a[i][0], acc[i][jn], 0, 0, 0);
-  };
-  f16x8 rg[HNDMA];
-  auto gload = [&](int kt) {
-#pragma unroll
-    for (int j = 0; j < HNDMA; ++j) rg[j] = *reinterpret_cast<const f16x8*>(src[j] + kt * kstep[j]);
-  };
-  auto lwrite = [&](unsigned char* stage) {
-#pragma unroll
-    for (int j = 0; j < HNDMA; ++j) *reinterpret_cast<f16x8*>(stage + lds_off[j] + lane * 16) = rg[j];
-  };
-  f16x8 w0[2][NJ], a0[2][2], w1[2][(TN == 128 || V == 16) ? NJ : 1], a1[2][2];
-  // probes 14 / 15: one k16 step (fragments + its 24 MFMAs) with the next stage's DMA instructions threaded between the MFMAs:
-  // 14: instruction j behind MFMA j + 1 of step 0 (j = 0..7); 15: instruction 4 s + 0..3 behind MFMAs 3, 9, 15, 21 of step s
-  auto kstep_spread = [&](const unsigned char* stage, unsigned char* other, int kt_next, bool more, int s, f16x8 (&w)[2][NJ],
-                          f16x8 (&a)[2][2], bool read_frags = true) {
-    if (read_frags) frags(stage, s, w, a);
+  // One k16 step: transposed product (A operand = W rows); the three terms of a block go into the same accumulator, small ones
+  // first -- tail.head, head.tail, head.head -- and the blocks of the wave take turns, so no MFMA waits for the one before it
+  // on the same accumulator.  SPREAD (256-wide tile): DMA instruction 4 s + 0..3 of the next stage behind MFMAs 3, 9, 15, 21.
+  auto kstep16 = [&](const f16x8 (&w)[2][NJ], const f16x8 (&a)[2][2], unsigned char* other, int kt_next, bool more, int s) {
     int n = 0;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-      const int wp = p == 0 ? 1 : 0, ap = p == 1 ? 1 : 0;          // tail.head, head.tail, head.head: the order of mfmas()
+      const int wp = p == 0 ? 1 : 0, ap = p == 1 ? 1 : 0;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int jn = 0; jn < NJ; ++jn) {
           acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[wp][jn], a[i][ap], acc[i][jn], 0, 0, 0);
           ++n;
-          if (V == 14 ? (s == 0 && n <= HNDMA) : (n % 6 == 3)) {      // 15 / 16: behind every sixth MFMA
-            const int j = V == 14 ? n - 1 : (4 * s + n / 6) % HNDMA;
+          if (TN == 256 && n % 6 == 3) {
             __builtin_amdgcn_sched_barrier(0);
-            if (more)
-              __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + kt_next * kstep[j]), (lptr_t)(other + lds_off[j]), 16, 0, 0);
+            if (more) dma1(other, kt_next, (4 * s + n / 6) % HNDMA);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
     }
   };
-  auto ktile = [&](const unsigned char* stage, unsigned char* other, int kt_next, bool more, bool first, int sb) {
-    (void)sb;
-    if (V != 14 && V != 15 && V != 16 && more && ((V != 1 && V != 13) || kt_next < 2)) dma(other, kt_next);
-    VX_GSTAMP(sb >= 0, sb + 2);
-    if constexpr (TN == 128) {
-      if (V != 3 || first) {
-        frags(stage, 0, w0, a0);
-        frags(stage, 1, w1, a1);
-      }
-      VX_GSTAMP(sb >= 0, sb + 3);
-      mfmas(w0, a0);
-      mfmas(w1, a1);
-    } else if constexpr (V == 14 || V == 15) {
-      kstep_spread(stage, other, kt_next, more, 0, w0, a0);
-      kstep_spread(stage, other, kt_next, more, 1, w0, a0);
-    } else if constexpr (V == 16) {                 // 15 + both k16 steps' fragments requested up front (96 fragment registers)
+  f16x8 w0[2][NJ], a0[2][2], w1[2][TN == 128 ? NJ : 1], a1[2][2];
+  auto ktile = [&](const unsigned char* stage, unsigned char* other, int kt_next, bool more) {
+    if constexpr (TN == 128) {                     // both k16 steps' fragments up front, DMA of the next stage behind the rendezvous
+      if (more) dma(other, kt_next);
       frags(stage, 0, w0, a0);
       frags(stage, 1, w1, a1);
-      kstep_spread(stage, other, kt_next, more, 0, w0, a0, false);
-      kstep_spread(stage, other, kt_next, more, 1, w1, a1, false);
-    } else {                                        // 48 fragment registers: one k16 step at a time
+      kstep16(w0, a0, other, kt_next, more, 0);
+      kstep16(w1, a1, other, kt_next, more, 1);
+    } else {                                       // 48 fragment registers: one k16 step at a time
       frags(stage, 0, w0, a0);
-      mfmas(w0, a0);
+      kstep16(w0, a0, other, kt_next, more, 0);
       frags(stage, 1, w0, a0);
-      mfmas(w0, a0);
+      kstep16(w0, a0, other, kt_next, more, 1);
     }
-    VX_GSTAMP(sb >= 0, sb + 4);
   };
   auto rendezvous = [&]() {
-    if (V == 4) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
 
   const int nk = g.K / HK;
-  VX_GSTAMP(true, 12);
-  if constexpr ((V == 11 || V == 12) && TN == 128) {
-    gload(0);
-    lwrite(stage0);
-    if (nk > 1) gload(1);
-    for (int kt = 0; kt < nk; kt += 2) {
-      __syncthreads();
-      if (kt + 1 < nk) { lwrite(stage1); if (kt + 2 < nk) gload(kt + 2); }
-      frags(stage0, 0, w0, a0); frags(stage0, 1, w1, a1);
-      mfmas(w0, a0); mfmas(w1, a1);
-      if (kt + 1 < nk) {
-        __syncthreads();
-        if (kt + 2 < nk) { lwrite(stage0); if (kt + 3 < nk) gload(kt + 3); }
-        frags(stage1, 0, w0, a0); frags(stage1, 1, w1, a1);
-        mfmas(w0, a0); mfmas(w1, a1);
-      }
-    }
-  } else {
   dma(stage0, 0);
   for (int kt = 0; kt < nk; kt += 2) {
-    const bool st = V == 0 && kt == 8;              // dev builds: stamp k-steps 8 and 9
-    (void)st;
-    VX_GSTAMP(st, 0);
     rendezvous();
-    VX_GSTAMP(st, 1);
-    ktile(stage0, stage1, kt + 1, kt + 1 < nk, kt == 0, st ? 0 : -1);
+    ktile(stage0, stage1, kt + 1, kt + 1 < nk);
     if (kt + 1 < nk) {
-      VX_GSTAMP(st, 5);
       rendezvous();
-      VX_GSTAMP(st, 6);
-      ktile(stage1, stage0, kt + 2, kt + 2 < nk, false, st ? 5 : -1);
+      ktile(stage1, stage0, kt + 2, kt + 2 < nk);
     }
   }
-  }
-  VX_GSTAMP(true, 10);
-  if (V == 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
-
   // epilogue: C = accumulator * 2^-(sa + sw) (+ bias, activation, residual as in the bf16x3 kernels).
   // With g.out_planes set, the result is NOT written as fp32 rows: it is split on the spot into the f16x2 planes of the NEXT
   // GEMM's A operand (tile-major, K = this N), so linear1 -> linear2 needs neither an fp32 round trip of the [M][4096] hidden
@@ -407,7 +308,6 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_kernel(GemmX3
       }
     }
   }
-  VX_GSTAMP(true, 11);
 }
 
 // tn = 0: 256 x 256 tiles when N is a multiple of 256 (every projection of the model) and they still fill the chip at least once
@@ -416,42 +316,8 @@ void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s, int tn) {
   if (tn == 0) tn = (g.N % 256 == 0 && (long)((g.M + HM - 1) / HM) * (g.N / 256) >= 256) ? 256 : 128;
   const int tiles = ((g.M + HM - 1) / HM) * ((g.N + tn - 1) / tn);
   if (tiles <= 0) return;
-  if (tn == 256) hipLaunchKernelGGL((gemm_f16x2_kernel<0, 256>), dim3(tiles), dim3(512), 0, s, g);
-  else hipLaunchKernelGGL((gemm_f16x2_kernel<0, 128>), dim3(tiles), dim3(512), 0, s, g);
+  if (tn == 256) hipLaunchKernelGGL((gemm_f16x2_kernel<256>), dim3(tiles), dim3(512), 0, s, g);
+  else hipLaunchKernelGGL((gemm_f16x2_kernel<128>), dim3(tiles), dim3(512), 0, s, g);
 }
-
-#ifdef VX_DEV_PROBES   // timing probes: tools-only build (vall-e-x_amd/_build.py --dev), never in the product library
-void launch_gemm_f16x2_probe(const GemmX3Args& g, int variant, hipStream_t s) {
-  const int tiles = ((g.M + HM - 1) / HM) * ((g.N + 127) / 128);
-  if (tiles <= 0) return;
-  const dim3 grid(tiles), block(512);
-  if (variant == 1) hipLaunchKernelGGL((gemm_f16x2_kernel<1, 128>), grid, block, 0, s, g);
-  else if (variant == 2) hipLaunchKernelGGL((gemm_f16x2_kernel<2, 128>), grid, block, 0, s, g);
-  else if (variant == 3) hipLaunchKernelGGL((gemm_f16x2_kernel<3, 128>), grid, block, 0, s, g);
-  else if (variant == 5) hipLaunchKernelGGL((gemm_f16x2_kernel<5, 128>), grid, block, 0, s, g);
-  else if (variant == 6) hipLaunchKernelGGL((gemm_f16x2_kernel<6, 128>), grid, block, 0, s, g);
-  else if (variant == 7) hipLaunchKernelGGL((gemm_f16x2_kernel<7, 128>), grid, block, 0, s, g);
-  else if (variant == 8) hipLaunchKernelGGL((gemm_f16x2_kernel<8, 128>), grid, block, 0, s, g);
-  else if (variant == 9) hipLaunchKernelGGL((gemm_f16x2_kernel<9, 128>), grid, block, 0, s, g);
-  else if (variant == 10) hipLaunchKernelGGL((gemm_f16x2_kernel<10, 128>), grid, block, 0, s, g);
-  else if (variant == 11) hipLaunchKernelGGL((gemm_f16x2_kernel<11, 128>), grid, block, 0, s, g);
-  else if (variant == 12) hipLaunchKernelGGL((gemm_f16x2_kernel<12, 128>), grid, block, 0, s, g);
-  else if (variant == 13) hipLaunchKernelGGL((gemm_f16x2_kernel<13, 128>), grid, block, 0, s, g);
-  else if (variant == 14 || variant == 15) {                       // 256 x 256 tile kernels: their own grid; N must be a multiple of 256
-    const dim3 grid256(((g.M + HM - 1) / HM) * (g.N / 256));
-    if (g.N % 256 != 0) return;
-    if (variant == 14) hipLaunchKernelGGL((gemm_f16x2_kernel<14, 256>), grid256, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_f16x2_kernel<15, 256>), grid256, block, 0, s, g);
-  }
-  else if (variant == 16 || variant == 17 || variant == 18) {    // 16: see the kernel; 17 / 18: probes 1 / 2 (no DMA / no MFMAs) on the 256 x 256 tile
-    const dim3 grid256(((g.M + HM - 1) / HM) * (g.N / 256));
-    if (g.N % 256 != 0) return;
-    if (variant == 16) hipLaunchKernelGGL((gemm_f16x2_kernel<16, 256>), grid256, block, 0, s, g);
-    else if (variant == 17) hipLaunchKernelGGL((gemm_f16x2_kernel<1, 256>), grid256, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_f16x2_kernel<2, 256>), grid256, block, 0, s, g);
-  }
-  else hipLaunchKernelGGL((gemm_f16x2_kernel<4, 128>), grid, block, 0, s, g);
-}
-#endif
 
 }  // namespace vx

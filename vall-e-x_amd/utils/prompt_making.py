@@ -50,7 +50,11 @@ def tokenize_audio(tokenizer: AudioTokenizer, audio: Union[str, Tuple[np.ndarray
 
 
 def make_transcript(name, wav, sr, transcript: Optional[str] = None):
-    """utils/prompt_making.py:87-120 without Whisper: the transcript must be given; language from the detector hook."""
+    """utils/prompt_making.py:87-120 without Whisper: the transcript must be given; language from the detector hook.
+    Like the reference (:91-92, `wav /= wav.abs().max()` on the caller's FloatTensor) a waveform whose peak exceeds 1 is
+    normalised IN PLACE, so the audio that `tokenize_audio` encodes afterwards is the normalised one."""
+    if isinstance(wav, np.ndarray) and wav.size and float(np.abs(wav).max()) > 1:
+        wav /= np.abs(wav).max()
     if transcript is None or transcript == "":
         raise RuntimeError("no transcript given: the reference transcribes with Whisper here (utils/prompt_making.py:99-110), which "
                            "is outside this package; pass transcript=")
@@ -71,7 +75,7 @@ def make_prompt(name: str, audio_prompt_path: Union[str, Tuple[np.ndarray, int]]
     if codec is None:
         codec = AudioTokenizer(device=G.device, valle=G.model)
     wav_pr, sr = _load_wav(audio_prompt_path) if isinstance(audio_prompt_path, str) else audio_prompt_path
-    wav_pr = np.asarray(wav_pr, np.float32)
+    wav_pr = np.array(wav_pr, np.float32)                         # own copy: make_transcript may normalise it in place
     if wav_pr.ndim == 1:
         wav_pr = wav_pr[None]
     if wav_pr.shape[-1] / sr > 15:                                # :60-61
