@@ -155,11 +155,15 @@ def test_hip_encoder_matches_transformers_port():
         got = np.transpose(np.asarray(frames[0][0]), (0, 2, 1))         # (B, 8, T) -> (B, T, 8)
         assert got.shape == gold.shape
         emb = orc.embeddings(wav).numpy()
+        # integer output: the bar is equality.  Measured on MI355X (profiles/r03_rvq_ties.log): all 101 frames x 8 codebooks of
+        # both fixtures bit-identical, 0 frames decided by a near-tie.  The tie analysis stays as the failure diagnosis: it
+        # tells a legitimate fp32 near-tie of the nearest-codeword search (both candidates within 1e-4 relative of the float64
+        # minimum distance) from a real defect.
         ties = sum(_codes_agree_up_to_ties(got[b], gold[b], emb[b], dec) for b in range(got.shape[0]))
         frames = gold.shape[0] * gold.shape[1]
-        print(f"{name}: {frames - ties} of {frames} frames bit-identical on all 8 codebooks, {ties} decided by a near-tie "
-              f"(both candidates within 1e-4 relative of the float64 minimum distance)")
-        assert ties <= max(1, frames // 50), ties                         # near-ties: at most 2 % of the frames
+        print(f"{name}: {frames - ties} of {frames} frames bit-identical on all 8 codebooks, {ties} decided by a near-tie")
+        assert ties == 0, f"{ties} of {frames} frames differ from the port at a near-tie of the codeword search"
+        np.testing.assert_array_equal(got, gold)
 
 
 @pytest.mark.gpu

@@ -6,8 +6,10 @@ Why these exist: with >= 2 such rows in one call the packed row count is >= 1024
 the large-M GEMM path (engine.hip proj(): `gemm_f16x2`) and the NAR attention (`attn_full_h2`) at L ~ 983 -- the kernels that
 dominate the bench -- and `dec_attn` walks contexts 260 .. 1090.  The short goldens never reach any of that.
 
-Bars: token ids bit-exact (all 8 codebooks, all 600 frames); AR logits (every 50th step, teacher-forced) within 3e-4 abs of
-the reference's; NAR logits of all 7 stages (first 16 generated rows) within 5e-3 abs (logits std ~25, K = 1024).
+Bars: token ids bit-exact (all 8 codebooks, all 600 frames); AR logits (every 50th step, teacher-forced) within 2e-5 abs of
+the reference's; NAR logits of all 7 stages (first 16 generated rows) within 6e-4 abs (logits std ~25, K = 1024).  Measured on
+MI355X (profiles/r03_logit_error.json, all three arithmetic modes alike): AR <= 5.6e-6, NAR <= 1.8e-4; the reference's own smallest
+decision margins in these goldens are 3.8e-5 (AR top-2 logit gap) and 5e-4 (NAR), so the bars sit BELOW the margins.
 """
 import numpy as np
 import pytest
@@ -17,6 +19,8 @@ from oracle.make_golden import FULL_CASES, FULL_LOGIT_EVERY, case_inputs
 from tests._util import get_model, golden
 
 pytestmark = pytest.mark.gpu
+
+AR_TOL, NAR_TOL = 2e-5, 6e-4
 
 GREEDY = [n for n in FULL_CASES if FULL_CASES[n]["top_k"] == 1]
 TOPK = [n for n in FULL_CASES if FULL_CASES[n]["top_k"] == 10]
@@ -80,7 +84,7 @@ def test_full_length_rows_batched_match_reference(names):
 
 @pytest.mark.parametrize("name", ["nl12_full_en_greedy", "nl12_full_ja_topk10"])
 def test_full_length_teacher_forced_logits(name):
-    """feed the reference's own 600 tokens through the cached decode step: logits at every 50th step within 3e-4 of the
+    """feed the reference's own 600 tokens through the cached decode step: logits at every 50th step within AR_TOL of the
     reference's, and for the greedy case the arg-max reproduces the reference token at EVERY step."""
     c, row, _ = _row(name)
     g = golden(name)
@@ -94,7 +98,7 @@ def test_full_length_teacher_forced_logits(name):
         if t % FULL_LOGIT_EVERY == 0:
             ref = g["ar_logits"][t // FULL_LOGIT_EVERY]
             worst = max(worst, float(np.abs(lg - ref).max()))
-            np.testing.assert_allclose(lg, ref, atol=3e-4, rtol=0, err_msg=f"step {t}")
+            np.testing.assert_allclose(lg, ref, atol=AR_TOL, rtol=0, err_msg=f"step {t}")
         if c["top_k"] == 1:
             assert int(np.argmax(lg)) == int(codes0[t]), f"step {t} (reference margin {g['ar_margin'][t]:.3e})"
         eng.ar_step(np.array([codes0[t]], np.int32))
@@ -103,7 +107,7 @@ def test_full_length_teacher_forced_logits(name):
 
 @pytest.mark.parametrize("name", ["nl12_full_en_greedy", "nl12_full_zh_topk10"])
 def test_full_length_nar_logits_all_stages(name):
-    """NAR stages on the reference's first codebook: all 7 stages' logits (first 16 generated rows) within 5e-3 of the
+    """NAR stages on the reference's first codebook: all 7 stages' logits (first 16 generated rows) within NAR_TOL of the
     reference's, and codebooks 2..8 bit-exact, at Ltot ~ 983 (one row -> register-staged GEMM) ..."""
     c, row, _ = _row(name)
     g = golden(name)
@@ -112,7 +116,7 @@ def test_full_length_nar_logits_all_stages(name):
     T = g["codes"].shape[1]
     for st in range(7):
         lg = m.engine.read_tap(f"nar_logits{st}", T * 1024).reshape(T, 1024)
-        np.testing.assert_allclose(lg[:16], g["nar_logits"][st], atol=5e-3, rtol=0, err_msg=f"stage {st}")
+        np.testing.assert_allclose(lg[:16], g["nar_logits"][st], atol=NAR_TOL, rtol=0, err_msg=f"stage {st}")
     np.testing.assert_array_equal(codes, g["codes"][0])
 
 
@@ -127,7 +131,7 @@ def test_full_length_nar_logits_batched_dma_gemm():
     T = [g["codes"].shape[1] for g in gs]
     for st in range(7):
         lg = m.engine.read_tap(f"nar_logits{st}", sum(T) * 1024).reshape(sum(T), 1024)
-        np.testing.assert_allclose(lg[:16], gs[0]["nar_logits"][st], atol=5e-3, rtol=0, err_msg=f"stage {st} row 0")
-        np.testing.assert_allclose(lg[T[0]:T[0] + 16], gs[1]["nar_logits"][st], atol=5e-3, rtol=0, err_msg=f"stage {st} row 1")
+        np.testing.assert_allclose(lg[:16], gs[0]["nar_logits"][st], atol=NAR_TOL, rtol=0, err_msg=f"stage {st} row 0")
+        np.testing.assert_allclose(lg[T[0]:T[0] + 16], gs[1]["nar_logits"][st], atol=NAR_TOL, rtol=0, err_msg=f"stage {st} row 1")
     for cd, g in zip(codes, gs):
         np.testing.assert_array_equal(cd, g["codes"][0])

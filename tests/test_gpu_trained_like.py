@@ -13,8 +13,9 @@ from tests._util import assert_codes, case_model, golden, inputs_row, nar_logit_
 pytestmark = pytest.mark.gpu
 
 KW = dict(max_new=608, max_prompt=400, max_text=256, max_batch=4)
-# abs tolerances on logits with std ~9 (AR) / ~45 (NAR) and |max| ~40 / ~250: ~1e-5 relative, the fp32 reassociation noise
-AR_TOL, NAR_TOL = 3e-3, 3e-2
+# abs tolerances on logits with std ~9 (AR) / ~48 (NAR) and |max| ~35 / ~220; measured on MI355X 6.1e-5 / 6.2e-4 in every
+# arithmetic mode (profiles/r03_logit_error.json); the reference's smallest margins here are 8.5e-3 (AR) / 1.8e-3 (NAR)
+AR_TOL, NAR_TOL = 2e-4, 2e-3
 
 
 @pytest.mark.parametrize("arith", ["f16x2", "bf16x3", "f32"])

@@ -96,23 +96,30 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  f32x4 w[8], x[8];
-  // x first: it is L2-resident and returns early, so the MFMAs can start as soon as the first weight tile lands
-#define VX_SK_LOAD(I)                                                                              \
-  _Pragma("unroll") for (int u = 0; u < 8; ++u) x[u] = xq[(long)((I) + u) * 64];                    \
-  _Pragma("unroll") for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + (long)((I) + u) * 64);
-  VX_SK_LOAD(0)
+  f32x4 w[8], x[8], w2[8], x2[8];
+  // x first: it is L2-resident and returns early, so the MFMAs can start as soon as the first weight tile lands.  Two register
+  // buffers: the loads of round r + 1 are requested BEFORE the MFMAs of round r (linear2, K = 4096, has two rounds per wave; a
+  // single buffer left HBM idle for the length of a round's 32 MFMAs).  Same MFMA sequence either way.
+#define VX_SK_LOAD(WW, XX, I)                                                                      \
+  _Pragma("unroll") for (int u = 0; u < 8; ++u) XX[u] = xq[(long)((I) + u) * 64];                   \
+  _Pragma("unroll") for (int u = 0; u < 8; ++u) WW[u] = __builtin_nontemporal_load(wp + (long)((I) + u) * 64);
+#define VX_SK_MFMA(WW, XX)                                                                         \
+  _Pragma("unroll") for (int u = 0; u < 8; ++u)                                                     \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(WW[u][j], XX[u][j], acc, 0, 0, 0);
+  VX_SK_LOAD(w, x, 0)
   VX_STAMP(stype_, 1);
   for (int i = 0;;) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[u][j], x[u][j], acc, 0, 0, 0);
+    if (i + 8 < kb_per_wave) { VX_SK_LOAD(w2, x2, i + 8) }
+    VX_SK_MFMA(w, x)
     i += 8;
     if (i >= kb_per_wave) break;
-    VX_SK_LOAD(i)
+    if (i + 8 < kb_per_wave) { VX_SK_LOAD(w, x, i + 8) }
+    VX_SK_MFMA(w2, x2)
+    i += 8;
+    if (i >= kb_per_wave) break;
   }
 #undef VX_SK_LOAD
+#undef VX_SK_MFMA
   VX_STAMP(stype_, 2);
 
   // acc[r] = out[b = lane&31][n = nt*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)].  The four waves' partial sums are combined
@@ -412,20 +419,32 @@ __device__ __forceinline__ void sb_reduce_ln_row(bool live, const float* __restr
 
 // attention output of row m from the context-split partials: the body of dec_attn_combine_kernel (thread tt -> head tt >> 4,
 // float4 chunk tt & 15; splits in ascending order, ot / lt per element)
-__device__ __forceinline__ void sb_combine_row(const float* __restrict__ part_o, const float* __restrict__ part_ml, int nsplit, int m,
+// NS (the number of context splits) is a compile-time constant so that all 2 NS loads are requested together: a runtime loop
+// walked the splits one memory round trip at a time, twice (10.2 us per out_proj launch at batch 1, profiles/r03_b1_kernel_stats_v1.csv)
+template <int NS>
+__device__ __forceinline__ void sb_combine_row(const float* __restrict__ part_o, const float* __restrict__ part_ml, int m,
                                                int tt, float* __restrict__ xs_row) {
   const int h = tt >> 4, c = tt & 15;
-  const long pi = (long)(m * N_HEAD + h) * nsplit;
+  const long pi = (long)(m * N_HEAD + h) * NS;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 ml[NS];
+  f32x4 po[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    ml[s] = *reinterpret_cast<const f32x2*>(part_ml + (pi + s) * 2);
+    po[s] = *reinterpret_cast<const f32x4*>(part_o + (pi + s) * D_HEAD + c * 4);
+  }
   float mt = NEG_BIG;
-  for (int s = 0; s < nsplit; ++s) mt = fmaxf(mt, part_ml[(pi + s) * 2]);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) mt = fmaxf(mt, ml[s][0]);
   float lt = 0.f;
   f32x4 ot = {0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < nsplit; ++s) {
-    const float a = expf(part_ml[(pi + s) * 2] - mt);
-    lt += part_ml[(pi + s) * 2 + 1] * a;
-    const f32x4 o = *reinterpret_cast<const f32x4*>(part_o + (pi + s) * D_HEAD + c * 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) ot[e] += o[e] * a;
+  for (int s = 0; s < NS; ++s) {
+    const float a = expf(ml[s][0] - mt);
+    lt += ml[s][1] * a;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ot[e] += po[s][e] * a;
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) ot[e] = ot[e] / lt;
@@ -433,7 +452,8 @@ __device__ __forceinline__ void sb_combine_row(const float* __restrict__ part_o,
 }
 
 // skinny_gemm_kernel (K = 1024) whose x operand is computed by the prologue.  MODE 0: rows = LN(resid + sum of SK slabs + bias);
-// MODE 1: rows = combine of the dec_attn partials (SK unused).  The first weight tile is requested BEFORE the prologue.
+// MODE 1: rows = combine of the dec_attn partials (SK = the number of context splits).  The first weight tile is requested BEFORE
+// the prologue.
 template <int MODE, int SK>
 __global__ __launch_bounds__(256) void skinny_gemm_sb_kernel(const float* __restrict__ Wp, float* __restrict__ out, int Npad, int splitk,
                                                              const float* __restrict__ partial, int pnpad, const float* __restrict__ bias,
@@ -457,7 +477,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_sb_kernel(const float* __rest
   const bool first = blockIdx.x == 0 && blockIdx.y == 0;
   for (int m = 0; m < M; ++m) {
     if (MODE == 0) sb_reduce_ln_row<SK>(true, partial, pnpad, bias, resid, first ? h_out : nullptr, g, bb, m, threadIdx.x, st, xs[m]);
-    else sb_combine_row(part_o, part_ml, nsplit, m, threadIdx.x, xs[m]);
+    else sb_combine_row<SK>(part_o, part_ml, m, threadIdx.x, xs[m]);
   }
   __syncthreads();
   // x fragment of lane (b = lane & 31, hi = lane >> 5) for k-block kb: x[b][8 kb + 4 hi ..]; rows >= M are zero columns of the MFMA
@@ -507,8 +527,13 @@ void launch_skinny_gemm_sb_ln(const float* Wp, float* partial_out, int Npad, int
 
 void launch_skinny_gemm_sb_combine(const float* Wp, float* partial_out, int Npad, int splitk, const float* part_o, const float* part_ml,
                                    int nsplit, int batch, hipStream_t s) {
-  hipLaunchKernelGGL((skinny_gemm_sb_kernel<1, 1>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, nullptr, 0,
-                     nullptr, nullptr, nullptr, nullptr, nullptr, part_o, part_ml, nsplit, batch);
+  if (nsplit == 16)
+    hipLaunchKernelGGL((skinny_gemm_sb_kernel<1, 16>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, nullptr, 0,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, part_o, part_ml, nsplit, batch);
+  else if (nsplit == 8)
+    hipLaunchKernelGGL((skinny_gemm_sb_kernel<1, 8>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, nullptr, 0,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, part_o, part_ml, nsplit, batch);
+  else { fprintf(stderr, "launch_skinny_gemm_sb_combine: %d context splits are not compiled in (8 or 16)\n", nsplit); abort(); }
 }
 
 // skinny16_relu_pack_kernel (linear1) with the reduce + residual + LayerNorm of its input rows as prologue; rows 16..31 of the

@@ -453,6 +453,7 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
   c->cur_batch = nrows;
   // enough (row, head, split) 8-wave workgroups to put >= 2 on every CU; one split (no combine launch) from 32 rows up
   c->nsplit = std::max(1, std::min(16, 512 / (nrows * N_HEAD)));
+  if (c->sb_fuse && nrows <= SB_ROWS) c->nsplit = nrows <= 2 ? 16 : 8;      // the small-batch out_proj prologue compiles the split count in
 
   launch_embed_rows(c->fx, mb.dev(o_dt), W(c, "ar_text_embedding.word_embeddings.weight"), mb.dev(o_it),
                     W(c, "ar_language_embedding.word_embeddings.weight"), mb.dev(o_lt), W(c, "ar_text_position.alpha"),
