@@ -14,7 +14,7 @@
 // The softmax runs on the scaled scores: exp((S' - M') 2^-10) with the 2^-10 folded into the exp constants (exact), and the
 // 2^14 of P comes from lowering the subtracted maximum by 14 ln2 (a common factor of a tile's p and of the running sum: it
 // cancels in O / l).  P <= 2^14 and |q|/8, |k|, |v| < 2047 keep every head inside fp16; a head that does not fit (inf) turns the
-// output into NaN, which the epilogue reports through the range flag -- the engine fails loudly, naming VX_ATTN_X3 / VX_ATTN_F32.
+// output into NaN, which the epilogue reports through the range flag -- the engine then re-runs the phase on the exact-fp32 kernels.
 // K/V tiles are split by the staging threads on their way global -> LDS (each value once per workgroup).  V is written
 // TRANSPOSED, two keys per ds_write_b32, with the key order inside a row permuted so that the 8 keys one lane contracts
 // in k-step s (the C-layout rows 16 s + 4 hi + {0..3, 8..11} of S^T, which are the P registers 8 s .. 8 s + 7) are one
