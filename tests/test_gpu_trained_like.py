@@ -47,3 +47,31 @@ def test_trained_like_logits(arith):
     assert max(errs) <= NAR_TOL, errs
     np.testing.assert_array_equal(codes, g["codes"][0])
     print(f"{name} [{arith}]: AR max |logit - ref| {worst:.2e}; NAR per stage {['%.1e' % e for e in errs]}")
+
+
+@pytest.mark.parametrize("name,nrows,slot", [("nl12_trained_en_greedy", 32, 11), ("nl12_trained_zh_topk10", 8, 6)])
+def test_trained_like_row_inside_a_batch(name, nrows, slot):
+    """the same golden rows through the other two decode chains: 32 rows (one context split, out_proj fused into dec_attn, 16 head
+    slabs) and 8 rows (context-split dec_attn + combine + separate out_proj) -- alone they take the small-batch chain"""
+    from oracle import synth
+    c = TRAINED_CASES[name]
+    g = golden(name)
+    row, us = inputs_row(c)
+    m = case_model(c, max_new=608, max_prompt=400, max_text=256, max_batch=32)
+    rows, cols = [], []
+    rng = np.random.default_rng(5)
+    for i in range(nrows):
+        if i == slot:
+            rows.append(row)
+            cols.append(us if us is not None else np.zeros(4096, np.float32))
+            continue
+        tp, sp = int(rng.integers(150, 300)), int(rng.integers(20, 80))
+        a, t = synth.synth_prompt(tp, sp, seed=61_000 + i)
+        lang = ("en", "zh", "ja")[i % 3]
+        rows.append(dict(text=np.concatenate([t[0], synth.synth_text(100, 61_000 + i)]), prompt=a[0], enroll=sp, prompt_language=lang,
+                         text_language=lang))
+        cols.append(synth.uniforms(4096, 1, 62_000 + i)[:, 0])
+    outs = m.inference_batch(rows, top_k=c["top_k"], uniforms=None if us is None else np.stack(cols, axis=1),
+                             force_eos_at=c["force_eos_at"])
+    assert m.engine.last_fallbacks()["lifetime"] == 0
+    assert_codes(f"{name} as row {slot} of {nrows}", outs[slot], g)
