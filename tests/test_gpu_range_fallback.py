@@ -74,3 +74,36 @@ def test_in_range_weights_never_fall_back_and_fp32_mode_has_no_guard():
     out = _run(m32, c2, [row], None if us is None else us[:, None])[0]
     assert m32.engine.last_fallbacks()["lifetime"] == 0
     assert_codes("nl2_range_v in fp32 mode", out, golden(base))
+
+
+def test_fallback_with_best_of_beams_and_continual():
+    """the two other callers of the guarded phases: best_of = 3 (ONE shared prefill broadcast to three decode rows, re-run in fp32
+    before the beams start) and VALLE.continual (NAR only, vx_nar)"""
+    from oracle import synth
+    from oracle.make_golden import CASES, CONTINUAL_CASES, continual_inputs
+    from tests import _util
+    for name in ("nl2_bestof3", "nl2_bestof3_worst"):
+        c = CASES[name]
+        _, row, us = _util.case_row(name)
+        sd = synth.out_of_range_state_dict(synth.vallex_state_dict(c["num_layers"], c["seed"], c["eos_gain"]), c["num_layers"], "ffn")
+        m = _util.VALLE(1024, 16, c["num_layers"], norm_first=True, add_prenet=False, prefix_mode=1, share_embedding=True,
+                        nar_scale_factor=1.0, prepend_bos=True, num_quantizers=8, engine_max_new=320, engine_max_prompt=400,
+                        engine_max_text=256, engine_max_batch=4)
+        m.to("cuda:0").load_state_dict(sd, strict=True)
+        out = m.inference(row["text"][None], np.array([len(row["text"])]), row["prompt"][None], row["enroll"], top_k=c["top_k"],
+                          prompt_language=row["prompt_language"], text_language=row["text_language"], uniforms=us,
+                          force_eos_at=c["force_eos_at"], best_of=c["best_of"], length_penalty=c.get("length_penalty", 1.0),
+                          return_worst=c.get("return_worst", False))
+        fb = m.engine.last_fallbacks()
+        assert fb["prefill"] == 1 and fb["nar"] == 1, fb
+        np.testing.assert_array_equal(out.numpy(), golden(name)["codes"])
+    cc = CONTINUAL_CASES["nl2_continual"]
+    sd = synth.out_of_range_state_dict(synth.vallex_state_dict(cc["num_layers"], cc["seed"], cc["eos_gain"]), cc["num_layers"], "v")
+    m = _util.VALLE(1024, 16, cc["num_layers"], norm_first=True, add_prenet=False, prefix_mode=1, share_embedding=True,
+                    nar_scale_factor=1.0, prepend_bos=True, num_quantizers=8, engine_max_new=320, engine_max_prompt=400,
+                    engine_max_text=256, engine_max_batch=4)
+    m.to("cuda:0").load_state_dict(sd, strict=True)
+    text, y = continual_inputs(cc)
+    out = m.continual(text, np.array([text.shape[-1]]), y)
+    assert m.engine.last_fallbacks() == dict(prefill=0, nar=1, lifetime=1)
+    np.testing.assert_array_equal(np.asarray(out), golden("nl2_continual")["codes"])
