@@ -29,8 +29,11 @@ Pinning status
     `transformers` port of the package's head code (`Xcodec2ISTFTHead`: Linear ->
     exp/clip -> polar -> vocos.spectral_ops.ISTFT(padding="same"), every sample,
     edges included); the backbone and `codes_to_features` == the same weights in
-    torch.nn modules wired as recalled -- the backbone's wiring
-    itself therefore still rests on the recalled structure.
+    torch.nn modules wired as recalled; the residual branch of
+    a ConvNeXt block == transformers' `Qwen3OmniMoeConvNeXtBlock` (a third-party
+    1-D ConvNeXt block of the same lineage).  Still recalled only: the order
+    embed conv -> AdaLayerNorm -> blocks -> final LayerNorm, and the block norm
+    being the id-conditioned AdaLayerNorm.
 
 The oracle keeps a real KV cache and only embeds the newest token per step; the
 reference re-embeds all of `y` and rebuilds the mask every step
@@ -344,20 +347,24 @@ class VocosOracle:
         x = F.layer_norm(x, (c,), eps=1e-6)
         return x * self.w[prefix + ".scale.weight"][bid] + self.w[prefix + ".shift.weight"][bid]
 
+    def convnext_branch(self, x: torch.Tensor, i: int, bid: int) -> torch.Tensor:
+        """the residual branch of ConvNeXt block i on x (B, C, T): depthwise conv k7 (centred) -> AdaLayerNorm -> Linear -> GELU (erf)
+        -> Linear -> gamma.  Operation order pinned against a third-party 1-D ConvNeXt block (tests/test_vocos_oracle_pieces.py)."""
+        p = f"backbone.convnext.{i}."
+        c = x.shape[1]
+        y = F.conv1d(x, self.w[p + "dwconv.weight"], self.w[p + "dwconv.bias"], padding=3, groups=c)
+        y = self._adaln(y.transpose(1, 2), p + "norm", bid)
+        y = F.linear(y, self.w[p + "pwconv1.weight"], self.w[p + "pwconv1.bias"])
+        y = F.gelu(y)
+        y = F.linear(y, self.w[p + "pwconv2.weight"], self.w[p + "pwconv2.bias"])
+        return (self.w[p + "gamma"] * y).transpose(1, 2)
+
     def backbone(self, feat: torch.Tensor, bid: int) -> torch.Tensor:
         c = synth.VOCOS_DIM
         x = F.conv1d(feat, self.w["backbone.embed.weight"], self.w["backbone.embed.bias"], padding=3)
         x = self._adaln(x.transpose(1, 2), "backbone.norm", bid).transpose(1, 2)
         for i in range(synth.VOCOS_LAYERS):
-            p = f"backbone.convnext.{i}."
-            r = x
-            x = F.conv1d(x, self.w[p + "dwconv.weight"], self.w[p + "dwconv.bias"], padding=3, groups=c)
-            x = self._adaln(x.transpose(1, 2), p + "norm", bid)
-            x = F.linear(x, self.w[p + "pwconv1.weight"], self.w[p + "pwconv1.bias"])
-            x = F.gelu(x)
-            x = F.linear(x, self.w[p + "pwconv2.weight"], self.w[p + "pwconv2.bias"])
-            x = self.w[p + "gamma"] * x
-            x = r + x.transpose(1, 2)
+            x = x + self.convnext_branch(x, i, bid)
         return F.layer_norm(x.transpose(1, 2), (c,), self.w["backbone.final_layer_norm.weight"],
                             self.w["backbone.final_layer_norm.bias"], 1e-6)
 

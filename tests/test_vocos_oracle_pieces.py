@@ -141,3 +141,40 @@ def test_istft_head_equals_transformers_port_of_the_vocos_head():
             o = torch.nn.functional.linear(x, orc.w["head.out.weight"], orc.w["head.out.bias"])
             assert float(o[..., : NB // 2].max()) > np.log(1e2)
         np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=2e-6 * max(scale, 1.0), rtol=1e-5)
+
+
+def test_convnext_branch_matches_a_third_party_convnext_1d_block():
+    """The ConvNeXt block of the backbone against an implementation that is not ours and not recalled: the installed `transformers`
+    ships `Qwen3OmniMoeConvNeXtBlock` (models/qwen3_omni_moe, the code2wav vocoder), the 1-D ConvNeXt block of the same lineage --
+    depthwise Conv1d k = 7 -> LayerNorm(eps 1e-6) over channels -> Linear(C, 4C) -> GELU (erf) -> Linear(4C, C) -> gamma -> + input.
+    Differences that the comparison removes: its depthwise conv is CAUSAL (6 frames of left padding) where Vocos centres it
+    (padding 3), so its branch output at frame t + 3 is the centred one at t (interior frames); its LayerNorm is a plain affine
+    one, which equals AdaLayerNorm with weight = scale[id], bias = shift[id]; its hidden width is 4C (the oracle is shape-agnostic).
+    Pins the operation order, the LayerNorm epsilon, the exact GELU and the placement of gamma of `VocosOracle.convnext_branch`."""
+    from transformers.models.qwen3_omni_moe.modeling_qwen3_omni_moe import Qwen3OmniMoeConvNeXtBlock
+    torch.manual_seed(5)
+    Cq, T, bid = synth.VOCOS_DIM, 40, 2
+    blk = Qwen3OmniMoeConvNeXtBlock(Cq).eval()
+    with torch.no_grad():
+        for prm in blk.parameters():
+            prm.copy_(torch.randn_like(prm) * 0.2)
+        blk.norm.weight.copy_(1.0 + 0.1 * torch.randn(Cq))
+        blk.gamma.copy_(0.3 * torch.randn(Cq))
+    scale = torch.zeros(4, Cq)
+    shift = torch.zeros(4, Cq)
+    scale[bid], shift[bid] = blk.norm.weight.detach(), blk.norm.bias.detach()
+    sd = {"backbone.convnext.0.dwconv.weight": blk.dwconv.conv.weight.detach().numpy(),
+          "backbone.convnext.0.dwconv.bias": blk.dwconv.conv.bias.detach().numpy(),
+          "backbone.convnext.0.norm.scale.weight": scale.numpy(), "backbone.convnext.0.norm.shift.weight": shift.numpy(),
+          "backbone.convnext.0.pwconv1.weight": blk.pwconv1.weight.detach().numpy(),
+          "backbone.convnext.0.pwconv1.bias": blk.pwconv1.bias.detach().numpy(),
+          "backbone.convnext.0.pwconv2.weight": blk.pwconv2.weight.detach().numpy(),
+          "backbone.convnext.0.pwconv2.bias": blk.pwconv2.bias.detach().numpy(),
+          "backbone.convnext.0.gamma": blk.gamma.detach().numpy()}
+    orc = VocosOracle(sd)
+    x = torch.randn(2, Cq, T)
+    with torch.no_grad():
+        theirs = blk(x) - x                                   # residual branch, causal: frame t + 3 <-> centred frame t
+        ours = orc.convnext_branch(x, 0, bid)
+    np.testing.assert_allclose(ours[:, :, 3: T - 3].numpy(), theirs[:, :, 6:].numpy(), atol=2e-5, rtol=0)
+    assert float(ours.abs().max()) > 0.1                      # a non-trivial branch
