@@ -454,8 +454,7 @@ __device__ __forceinline__ void sb_combine_row(const float* __restrict__ part_o,
 // skinny_gemm_kernel (K = 1024) whose x operand is computed by the prologue.  MODE 0: rows = LN(resid + sum of SK slabs + bias);
 // MODE 1: rows = combine of the dec_attn partials (SK = the number of context splits).  The first weight tile is requested BEFORE
 // the prologue.
-// ROWS = rows of the LDS image (MODE 1 also serves 5 .. SB_COMBINE_ROWS rows: the combine of a row is 16 heads x NS partials, 17 KB)
-template <int MODE, int SK, int ROWS>
+template <int MODE, int SK>
 __global__ __launch_bounds__(256) void skinny_gemm_sb_kernel(const float* __restrict__ Wp, float* __restrict__ out, int Npad, int splitk,
                                                              const float* __restrict__ partial, int pnpad, const float* __restrict__ bias,
                                                              const float* __restrict__ resid, float* __restrict__ h_out,
@@ -463,7 +462,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_sb_kernel(const float* __rest
                                                              const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                              int nsplit, int M) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
-  __shared__ __attribute__((aligned(16))) float xs[ROWS][D_MODEL];
+  __shared__ __attribute__((aligned(16))) float xs[SB_MAX][D_MODEL];
   __shared__ float st[2][4];
   constexpr int K = D_MODEL;
   const int nt = blockIdx.x, ks = blockIdx.y;
@@ -518,25 +517,24 @@ void launch_skinny_gemm_sb_ln(const float* Wp, float* partial_out, int Npad, int
                               const float* bias, const float* resid, float* h_out, const float* g, const float* b, int batch,
                               hipStream_t s) {
   if (sk_in == 8)
-    hipLaunchKernelGGL((skinny_gemm_sb_kernel<0, 8, SB_MAX>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, partial_in,
+    hipLaunchKernelGGL((skinny_gemm_sb_kernel<0, 8>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, partial_in,
                        D_MODEL, bias, resid, h_out, g, b, nullptr, nullptr, 0, batch);
   else if (sk_in == 4)
-    hipLaunchKernelGGL((skinny_gemm_sb_kernel<0, 4, SB_MAX>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, partial_in,
+    hipLaunchKernelGGL((skinny_gemm_sb_kernel<0, 4>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, partial_in,
                        D_MODEL, bias, resid, h_out, g, b, nullptr, nullptr, 0, batch);
   else { fprintf(stderr, "launch_skinny_gemm_sb_ln: split-K factor %d of the producer is not compiled in\n", sk_in); abort(); }
 }
 
 void launch_skinny_gemm_sb_combine(const float* Wp, float* partial_out, int Npad, int splitk, const float* part_o, const float* part_ml,
                                    int nsplit, int batch, hipStream_t s) {
+  // (tried for 5 .. 8 rows as well -- BASELINE config 5 decodes 8 -- with 4 splits: 134.7 vs 138.5 audio-s/s, the 8-row prologue
+  // costs more than the combine launch it removes; DESIGN.md dead-end table)
   if (nsplit == 16 && batch <= SB_MAX)
-    hipLaunchKernelGGL((skinny_gemm_sb_kernel<1, 16, SB_MAX>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, nullptr, 0,
+    hipLaunchKernelGGL((skinny_gemm_sb_kernel<1, 16>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, nullptr, 0,
                        nullptr, nullptr, nullptr, nullptr, nullptr, part_o, part_ml, nsplit, batch);
   else if (nsplit == 8 && batch <= SB_MAX)
-    hipLaunchKernelGGL((skinny_gemm_sb_kernel<1, 8, SB_MAX>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, nullptr, 0,
+    hipLaunchKernelGGL((skinny_gemm_sb_kernel<1, 8>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, nullptr, 0,
                        nullptr, nullptr, nullptr, nullptr, nullptr, part_o, part_ml, nsplit, batch);
-  else if (nsplit == 4 && batch <= SB_COMBINE_ROWS)
-    hipLaunchKernelGGL((skinny_gemm_sb_kernel<1, 4, SB_COMBINE_ROWS>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk,
-                       nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, part_o, part_ml, nsplit, batch);
   else { fprintf(stderr, "launch_skinny_gemm_sb_combine: %d context splits x %d rows are not compiled in\n", nsplit, batch); abort(); }
 }
 

@@ -454,7 +454,6 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
   // enough (row, head, split) 8-wave workgroups to put >= 2 on every CU; one split (no combine launch) from 32 rows up
   c->nsplit = std::max(1, std::min(16, 512 / (nrows * N_HEAD)));
   if (c->sb_fuse && nrows <= SB_ROWS) c->nsplit = nrows <= 2 ? 16 : 8;      // the small-batch out_proj prologue compiles the split count in
-  else if (c->sb_fuse && nrows <= SB_COMBINE_ROWS) c->nsplit = 4;
 
   launch_embed_rows(c->fx, mb.dev(o_dt), W(c, "ar_text_embedding.word_embeddings.weight"), mb.dev(o_it),
                     W(c, "ar_language_embedding.word_embeddings.weight"), mb.dev(o_lt), W(c, "ar_text_position.alpha"),
@@ -577,15 +576,8 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
     if (fused) {
       launch_dec_reduce_ln_pack(c->p_oh, N_HEAD, D_MODEL, L.out_b, c->dh, c->dh, L.n2_w, L.n2_b, c->xp, nb, st);
     } else {
-      if (c->sb_fuse && c->nsplit == 4 && nb <= SB_COMBINE_ROWS) {
-        // 5 .. 8 rows: the combine of the context splits runs in the prologue of the out_proj GEMM (one launch less per layer)
-        ProfScope ps(c, 1);
-        launch_skinny_gemm_sb_combine(L.out_wp, c->p_o, D_MODEL, SK_OUT, c->part_o, c->part_ml, c->nsplit, nb, st);
-      } else {
-        if (c->nsplit > 1) launch_dec_attn_combine(c->part_o, c->part_ml, c->nsplit, c->active, c->xp_att, nb, st);
-        ProfScope ps(c, 1);
-        launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, st);
-      }
+      if (c->nsplit > 1) launch_dec_attn_combine(c->part_o, c->part_ml, c->nsplit, c->active, c->xp_att, nb, st);
+      { ProfScope ps(c, 1); launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, st); }
       launch_dec_reduce_ln_pack(c->p_o, SK_OUT, D_MODEL, L.out_b, c->dh, c->dh, L.n2_w, L.n2_b, c->xp, nb, st);
     }
     { ProfScope ps(c, 1); launch_skinny16_relu_pack(L.l1_wp, c->xp, L.l1_b, c->xp4, D_FF, D_MODEL, st); }

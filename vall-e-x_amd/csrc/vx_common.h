@@ -149,7 +149,6 @@ void launch_skinny16_relu_pack(const float* W16, const float* xp, const float* b
                                hipStream_t s);
 // small batches (<= SB_ROWS rows): the consumer GEMM computes its own input rows in its prologue (decode.hip)
 constexpr int SB_ROWS = 4;
-constexpr int SB_COMBINE_ROWS = 8;   // 5 .. 8 rows (BASELINE config 5 runs 8): only the context-split combine is folded (into out_proj)
 // partial_out[ks][b][n] = sum_k LN(resid[b] + sum_ks' partial_in[ks'][b] + bias)[k] W[n][k]   (K = 1024); workgroup 0 writes h_out
 void launch_skinny_gemm_sb_ln(const float* Wp, float* partial_out, int Npad, int splitk, const float* partial_in, int sk_in,
                               const float* bias, const float* resid, float* h_out, const float* g, const float* b, int batch,
