@@ -174,8 +174,17 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_probe_kernel(
         for (int jn = 0; jn < NJ; ++jn) {
           acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[wp][jn], a[i][ap], acc[i][jn], 0, 0, 0);
           ++n;
-          if (V == 14 ? (s == 0 && n <= HNDMA) : (n % 6 == 3)) {      // 15 / 16: behind every sixth MFMA
-            const int j = V == 14 ? n - 1 : (4 * s + n / 6) % HNDMA;
+          // 15 / 16: behind every sixth MFMA of the whole K tile; 20: behind every third MFMA of k16 step 0 (all eight requests in
+          // the FIRST half of the tile: each has >= 24 MFMA times to land before the next rendezvous); 21: every fourth MFMA, six in
+          // step 0 and two at the start of step 1; 22: every second MFMA of step 0 from the fourth on (first third of the tile)
+          const bool here = V == 14 ? (s == 0 && n <= HNDMA)
+                          : V == 20 ? (s == 0 && n % 3 == 0)
+                          : V == 21 ? (n % 4 == 0 && (s == 0 || n <= 8))
+                          : V == 22 ? (s == 0 && n >= 4 && n % 2 == 0 && n <= 18)
+                                    : (n % 6 == 3);
+          if (here) {
+            const int j = V == 14 ? n - 1 : V == 20 ? n / 3 - 1 : V == 21 ? (s == 0 ? n / 4 - 1 : 5 + n / 4) : V == 22 ? n / 2 - 2
+                                  : (4 * s + n / 6) % HNDMA;
             __builtin_amdgcn_sched_barrier(0);
             if (more)
               __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + kt_next * kstep[j]), (lptr_t)(other + lds_off[j]), 16, 0, 0);
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_probe_kernel(
   };
   auto ktile = [&](const unsigned char* stage, unsigned char* other, int kt_next, bool more, bool first, int sb) {
     (void)sb;
-    if (V != 14 && V != 15 && V != 16 && more && ((V != 1 && V != 13) || kt_next < 2)) dma(other, kt_next);
+    if (V != 14 && V != 15 && V != 16 && V != 20 && V != 21 && V != 22 && more && ((V != 1 && V != 13) || kt_next < 2)) dma(other, kt_next);
     VX_GSTAMP(sb >= 0, sb + 2);
     if constexpr (TN == 128) {
       if (V != 3 || first) {
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_probe_kernel(
       VX_GSTAMP(sb >= 0, sb + 3);
       mfmas(w0, a0);
       mfmas(w1, a1);
-    } else if constexpr (V == 14 || V == 15) {
+    } else if constexpr (V == 14 || V == 15 || V == 20 || V == 21 || V == 22) {
       kstep_spread(stage, other, kt_next, more, 0, w0, a0);
       kstep_spread(stage, other, kt_next, more, 1, w0, a0);
     } else if constexpr (V == 16) {                 // 15 + both k16 steps' fragments requested up front (96 fragment registers)
@@ -360,11 +369,14 @@ void launch_gemm_f16x2_probe(const GemmX3Args& g, int variant, hipStream_t s) {
     if (variant == 14) hipLaunchKernelGGL((gemm_f16x2_probe_kernel<14, 256>), grid256, block, 0, s, g);
     else hipLaunchKernelGGL((gemm_f16x2_probe_kernel<15, 256>), grid256, block, 0, s, g);
   }
-  else if (variant == 16 || variant == 17 || variant == 18 || variant == 19) {    // 19: the 256 x 256 kernel with the DMA instructions back to back (before round 3)    // 16: see the kernel; 17 / 18: probes 1 / 2 (no DMA / no MFMAs) on the 256 x 256 tile
+  else if (variant >= 16 && variant <= 22) {    // 19: the 256 x 256 kernel with the DMA instructions back to back (before round 3)    // 16: see the kernel; 17 / 18: probes 1 / 2 (no DMA / no MFMAs) on the 256 x 256 tile
     const dim3 grid256(((g.M + HM - 1) / HM) * (g.N / 256));
     if (g.N % 256 != 0) return;
     if (variant == 16) hipLaunchKernelGGL((gemm_f16x2_probe_kernel<16, 256>), grid256, block, 0, s, g);
     else if (variant == 19) hipLaunchKernelGGL((gemm_f16x2_probe_kernel<0, 256>), grid256, block, 0, s, g);
+    else if (variant == 20) hipLaunchKernelGGL((gemm_f16x2_probe_kernel<20, 256>), grid256, block, 0, s, g);
+    else if (variant == 21) hipLaunchKernelGGL((gemm_f16x2_probe_kernel<21, 256>), grid256, block, 0, s, g);
+    else if (variant == 22) hipLaunchKernelGGL((gemm_f16x2_probe_kernel<22, 256>), grid256, block, 0, s, g);
     else if (variant == 17) hipLaunchKernelGGL((gemm_f16x2_probe_kernel<1, 256>), grid256, block, 0, s, g);
     else hipLaunchKernelGGL((gemm_f16x2_probe_kernel<2, 256>), grid256, block, 0, s, g);
   }

@@ -19,7 +19,7 @@ for (N, K) in ((3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)):
     # 74 / 75 = probes 14 / 15: the 256 x 256 kernel with the LDS-DMA instructions issued between the MFMAs (behind the first eight /
     # behind every sixth; same sums as 8)
     for k, name in ((2, "x3-dma"), (6, "f16x2"), (7, "h2-256x128"), (8, "h2-256x256"), (74, "h2-256x256-dma-early"),
-                    (79, "h2-256x256-dma-b2b(r02)"), (75, "h2-256x256-dma-spread"), (76, "h2-256x256-dma-spread-frag2"), (77, "h2-256x256-noDMA"), (78, "h2-256x256-noMFMA"),
+                    (79, "h2-256x256-dma-b2b(r02)"), (75, "h2-256x256-dma-spread"), (80, "spread-first-half"), (81, "spread-3/4"), (82, "spread-first-third"), (76, "h2-256x256-dma-spread-frag2"), (77, "h2-256x256-noDMA"), (78, "h2-256x256-noMFMA"),
                     (61, "h2-noDMA"),
                     (62, "h2-noMFMA"), (63, "h2-nofrag"), (64, "h2-nobarrier")):
         us, md = eng.bench_gemm(M, N, K, k, 5)
