@@ -1,0 +1,51 @@
+"""CPU: the pieces of bench.py that decide what the JSON line CLAIMS -- the arithmetic label and whether a committed counter
+file may be quoted as `roofline.traffic` -- without a GPU."""
+import json
+import os
+import shutil
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_dtype_label_follows_the_engine_mode():
+    assert bench.dtype_label("f32", "f32") == "f32"                       # the reference's arithmetic end to end
+    d = bench.dtype_label("f16x2", "f16x2")
+    assert d.startswith("f32 (cached AR decode step) + f16x2") and "22 significant bits" in d and "fp32 accumulate" in d
+    m = bench.dtype_label("bf16x3", "f32")
+    assert "bf16x3" in m and "projections" in m and m.endswith("f32 full-sequence attention")
+    assert bench.dtype_label("stub", "stub") == "none (stub)"
+
+
+def test_counter_file_is_refused_when_the_kernel_source_changed(tmp_path, monkeypatch):
+    """tools/pmc_traffic.py stamps sha256(kernel translation unit + vx_common.h) into profiles/rNN_pmc_<kernel>.json; bench.py
+    quotes `traffic` only from a file whose stamp equals the digest of the source in THIS tree (the quoted file went
+    stale the moment a kernel changed)."""
+    fake = tmp_path / "repo"
+    csrc = fake / "vall-e-x_amd" / "csrc"
+    csrc.mkdir(parents=True)
+    (fake / "profiles").mkdir()
+    for f in ("decode.hip", "vx_common.h"):
+        shutil.copy(os.path.join(ROOT, "vall-e-x_amd", "csrc", f), csrc / f)
+    monkeypatch.setattr(bench, "ROOT", str(fake))
+    digest = bench.kernel_source_digest("dec_attn")
+    assert digest and len(digest) == 64 and bench.kernel_source_digest("no_such_kernel") is None
+    json.dump({"traffic_bytes_per_launch": 123, "source_sha256": digest}, open(fake / "profiles" / "r07_pmc_dec_attn.json", "w"))
+    json.dump({"traffic_bytes_per_launch": 1}, open(fake / "profiles" / "r02_pmc_dec_attn.json", "w"))     # older round, no stamp
+    pj, src, stale = bench.newest_pmc("dec_attn")
+    assert (pj["traffic_bytes_per_launch"], src, stale) == (123, os.path.join("profiles", "r07_pmc_dec_attn.json"), False)
+    with open(csrc / "decode.hip", "a") as fh:                             # the kernel changes ...
+        fh.write("\n// edited\n")
+    assert bench.newest_pmc("dec_attn")[2] is True                         # ... and the committed counters are refused
+    assert bench.newest_pmc("gemm_f16x2") == (None, None, False)           # no file at all
+
+
+def test_committed_counter_files_carry_a_stamp():
+    """every counter file of round 3 on names the source it was measured on (older rounds predate the stamp)"""
+    prof = os.path.join(ROOT, "profiles")
+    new = [f for f in os.listdir(prof) if f.startswith("r0") and "_pmc_" in f and f.endswith(".json") and f[:3] >= "r03"]
+    assert new, "no round-3 counter files"
+    for f in new:
+        pj = json.load(open(os.path.join(prof, f)))
+        assert len(pj.get("source_sha256", "")) == 64 and pj["traffic_bytes_per_launch"] > 0, f
