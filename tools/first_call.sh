@@ -5,6 +5,7 @@
 # in the build container first (tools/dev/ travels with the snapshot).
 cd "${GRAFT_REPO_ROOT:-.}" || exit 1
 mkdir -p gpurun_out
+python -c "import torch; print('devices visible:', torch.cuda.device_count())" 2>/dev/null; /opt/rocm/bin/rocminfo 2>/dev/null | grep -c "gfx950" | sed 's/^/rocminfo gfx950 lines: /'
 timeout 600 python -m pytest tests -m gpu -q -rf --durations=15 > gpurun_out/fc_gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -25 gpurun_out/fc_gpu_tests.log
 timeout 200 python bench.py > gpurun_out/fc_bench.json 2> gpurun_out/fc_bench.err; echo "bench rc=$?"; head -c 600 gpurun_out/fc_bench.json; echo
 if [ -f tools/dev/libvallex_hip.so ]; then
