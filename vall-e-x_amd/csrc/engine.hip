@@ -1446,14 +1446,14 @@ int vx_ar_prefill(vx_ctx* c, const vx_batch* b) {
   c->st_fb_prefill = c->st_fb_nar = 0;
   if (int e = ar_prefill(c, b, 0, b->batch)) return e;
   bool raised = false;
-  if (int e = take_range_flag(c, &raised)) return e;       // syncs
+  if (int e = take_range_flag(c, &raised)) return e;       // syncs when the mode is guarded
   if (raised) {
     ++c->st_fb_prefill; ++c->fb_total;
     if (int e = ensure_f32_buffers(c)) return e;
     F32Scope f32(c);
     if (int e = ar_prefill(c, b, 0, b->batch)) return e;
-    HIPCHK(hipStreamSynchronize(c->stream));
   }
+  HIPCHK(hipStreamSynchronize(c->stream));                 // the seam returns with the prefill complete in every mode
   HIPCHK(hipGetLastError());
   return VX_OK;
 }
