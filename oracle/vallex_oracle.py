@@ -84,6 +84,14 @@ class VallexOracle:
         self.d = synth.D_MODEL
         self.h = synth.N_HEAD
         self.pe = sine_pe(4000)
+        # optional operand statistics (a dict): running max |.| of what the f16x2 kernels of the HIP engine see as GEMM / attention
+        # operands on the FULL-SEQUENCE paths -- "ln" (LayerNorm outputs), "q8" (q / 8), "k", "v", "att" (attention output),
+        # "ffn" (ReLU'd hidden activations).  Their fp16 range at the activation scale 2^5 ends at 2047.
+        self.stats = None
+
+    def _stat(self, key, t):
+        if self.stats is not None and t.shape[0] > 1:                  # multi-row calls only: the cached decode step is exact fp32
+            self.stats[key] = max(self.stats.get(key, 0.0), float(t.abs().max()))
 
     # ---- building blocks -------------------------------------------------
     def _pe(self, n):
@@ -104,6 +112,7 @@ class VallexOracle:
         T = x.shape[0]
         qkv = F.linear(x, self.w[prefix + ".in_proj_weight"], self.w[prefix + ".in_proj_bias"])
         q, k, v = qkv.chunk(3, dim=-1)
+        self._stat("ln", x); self._stat("q8", q * 0.125); self._stat("k", k); self._stat("v", v)
         hd = self.d // self.h
         q = q.view(T, self.h, hd).transpose(0, 1)
         k = k.view(T, self.h, hd).transpose(0, 1)
@@ -116,11 +125,13 @@ class VallexOracle:
             att = att.masked_fill(mask, float("-inf"))
         att = F.softmax(att, dim=-1)
         y = (att @ v).transpose(0, 1).contiguous().view(T, self.d)
+        self._stat("att", y)
         y = F.linear(y, self.w[prefix + ".out_proj.weight"], self.w[prefix + ".out_proj.bias"])
         return y, (k, v)
 
     def _ffn(self, x, prefix):                         # modules/transformer.py:371-373 (ReLU :187)
         h = F.relu(F.linear(x, self.w[prefix + "linear1.weight"], self.w[prefix + "linear1.bias"]))
+        self._stat("ln", x); self._stat("ffn", h)
         return F.linear(h, self.w[prefix + "linear2.weight"], self.w[prefix + "linear2.bias"])
 
     def _ar_stack(self, x, mask, past, taps=None):

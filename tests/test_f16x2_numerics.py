@@ -123,3 +123,34 @@ def test_token_ids_survive_f16x2_projections(name, monkeypatch):
     finally:
         VO.F.linear = orig
     np.testing.assert_array_equal(out, np.load(os.path.join(GOLD, name + ".npz"))["codes"])
+
+
+def test_operand_headroom_of_the_f16x2_range():
+    """How far the operands of the f16x2 kernels are from the end of their fp16 range (|x| < 2047 at the activation scale 2^5),
+    measured on the oracle over a 12-layer AR prefill + one full NAR stage at the BASELINE shape (983 rows): default-init weights,
+    the trained-like weights (LayerNorm gains to 4, massive FFN channels, heavy tails) and, as the counter-example the engine's
+    fp32 fallback exists for, weights rescaled out of range.  The real checkpoint is not available offline; this is the margin the
+    two synthetic regimes leave."""
+    from oracle.make_golden import FULL_CASES, TRAINED_CASES, case_state_dict
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    out = {}
+    for label, c in (("default-init", FULL_CASES["nl12_full_en_greedy"]), ("trained-like", TRAINED_CASES["nl12_trained_en_greedy"])):
+        orc = VO.VallexOracle(case_state_dict(c), 12)
+        orc.stats = {}
+        a, t, text, pl, langs = case_inputs(c)
+        with torch.no_grad():
+            orc.ar_prefill(torch.from_numpy(text[0].astype(np.int64)), torch.from_numpy(a[0, :, 0].astype(np.int64)), t.shape[-1], pl, langs)
+            orc._nar_stack(torch.randn(983, 1024) * 2.0, orc.w["nar_stage_embeddings.0.word_embeddings.weight"])
+        out[label] = dict(orc.stats)
+        assert max(orc.stats.values()) < 2047.0, (label, orc.stats)
+    print("max |operand| seen by the f16x2 kernels (range ends at 2047):", {k: {n: round(v, 1) for n, v in d.items()} for k, d in out.items()})
+    assert out["trained-like"]["ffn"] > 4 * out["default-init"]["ffn"]            # the massive channels are there ...
+    assert max(out["trained-like"].values()) < 2047.0 / 2                          # ... with more than 2x headroom left
+    # counter-example: the 2^12 rescaling of 64 FFN channels (same fp32 function) leaves the range -> the engine re-runs in fp32
+    c = dict(CASES["nl2_topk10"], range_kind="ffn")
+    orc = VO.VallexOracle(case_state_dict(c), 2)
+    orc.stats = {}
+    a, t, text, pl, langs = case_inputs(c)
+    with torch.no_grad():
+        orc.ar_prefill(torch.from_numpy(text[0].astype(np.int64)), torch.from_numpy(a[0, :, 0].astype(np.int64)), t.shape[-1], pl, langs)
+    assert orc.stats["ffn"] > 2047.0
