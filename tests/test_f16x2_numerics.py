@@ -132,7 +132,6 @@ def test_operand_headroom_of_the_f16x2_range():
     fp32 fallback exists for, weights rescaled out of range.  The real checkpoint is not available offline; this is the margin the
     two synthetic regimes leave."""
     from oracle.make_golden import FULL_CASES, TRAINED_CASES, case_state_dict
-    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
     out = {}
     for label, c in (("default-init", FULL_CASES["nl12_full_en_greedy"]), ("trained-like", TRAINED_CASES["nl12_trained_en_greedy"])):
         orc = VO.VallexOracle(case_state_dict(c), 12)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """MFMA / VALU busy fractions of the matrix kernels from the three rocprofv3 --pmc passes of tools/pmc_mfma.sh
-(gpurun_out/pm_{1,2,3}.csv) -> JSON on stdout (kept as profiles/rNN_pmc_mfma_busy.json).
+(gpurun_out/pm_{1,2,3}.csv) -> JSON on stdout (kept as profiles/rNN_mfma_busy.json).
 
 Units (MI355X_MICROARCH.md, rocprofv3 PMC section): SQ_VALU_MFMA_BUSY_CYCLES counts shader cycles, summed over all SIMDs (exactly
 32 per v_mfma_f32_32x32x16_f16: the file shows BUSY / SQ_INSTS_MFMA = 32.0); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count
