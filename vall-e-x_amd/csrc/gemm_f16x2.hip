@@ -13,11 +13,11 @@
 // of this model are far inside; a device flag makes the engine re-run the phase in exact fp32 otherwise); weights are scaled
 // from their own max.  Tails below 2^-14 are fp16 subnormals (honoured by the matrix cores): <= 2^-25 * 2^-s absolute.
 //
-// Structure: tile 256 x 256 x 32 for every N that is a multiple of 256 (all projections of the model; 8 waves 4 x 2, wave tile
-// 64 x 128 = 8 accumulator blocks, 128 accumulator registers, fragments read one k16 step at a time) and 256 x 128 x 32 otherwise
-// / for row sets too short to fill the chip with 256-wide tiles (wave tile 64 x 64).  Operand tiles go global -> LDS with
-// global_load_lds_dwordx4 (no VGPR round trip) into two LDS stages of 64 / 48 KiB (2 planes x (256 + TN) rows x 64 B), the XOR
-// swizzle of the 64-B LDS rows applied on the global side.  256-wide tile: the eight DMA instructions a wave issues for the NEXT
+// Structure: tile 256 x 256 x 32 (8 waves 4 x 2, wave tile 64 x 128 = 8 accumulator blocks, 128 accumulator registers, fragments
+// read one k16 step at a time; one workgroup per CU) for the long row sets, tile 128 x 128 x 32 (4 waves 2 x 2, wave tile 64 x 64,
+// TWO workgroups per CU) for the short ones -- launch_gemm_f16x2 picks by a measured cost model; a 256 x 128 instantiation is kept
+// for A/B.  Operand tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR round trip) into two LDS stages of 64 / 32 KiB
+// (2 planes x (TM + TN) rows x 64 B), the XOR swizzle of the 64-B LDS rows applied on the global side.  256-wide tile: the eight DMA instructions a wave issues for the NEXT
 // stage are threaded between the MFMAs of this K tile (one behind every sixth MFMA) instead of back to back behind the rendezvous
 // with the matrix pipe idle: -2 .. -7 % on the four NAR shapes (profiles/r03_gemm_bench.log, columns h2-256x256 vs -dma-spread),
 // same sums.  The timing probes this kernel grew up with live in tools/dev_src/gemm_f16x2_probes.hip (tools-only build).
@@ -31,8 +31,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int HM = 256, HK = 32, HLD = 64;                       // TN (columns of a tile) = 128 or 256: template parameter
-constexpr int HA_PL = HM * HLD;                                  // 16 KiB per A plane and stage
+constexpr int HM = 256, HK = 32, HLD = 64;                       // rows of an A plane BLOCK (H2_TILE_A); tile rows / columns: template parameters
 constexpr int WTR = H2_TILE_W;                                   // rows of a W plane tile (256): a TN = 128 tile is half of one
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
@@ -100,10 +99,17 @@ void launch_absmax(const float* x, long n, unsigned* out_bits, hipStream_t s) {
   hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 2048)), dim3(256), 0, s, x, n, out_bits);
 }
 
-template <int TN>
-__global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
-  constexpr int HN = TN, HW_PL = TN * HLD, HSTAGE = 2 * HA_PL + 2 * HW_PL;     // 48 / 64 KiB per stage
-  constexpr int HNDMA = HSTAGE / (8 * 1024);                                    // 1 KiB DMA instructions per wave and stage: 6 / 8
+// TM = rows of a tile: 256 (8 waves, one workgroup per CU) or 128 (4 waves, 32 KiB stages, TWO workgroups per CU) -- the 128-row tile
+// is for row sets too short to fill the chip with 256-row tiles (one utterance: M = 983 gives 4 x N/128 workgroups on 256 CUs); its
+// A panel is the upper or lower half of a 256-row plane block.  Per output element the sequence of accumulations is the same for
+// every tile shape, so the result does not depend on which one runs.
+template <int TN, int TM>
+__global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_f16x2_kernel(GemmX3Args g) {
+  constexpr int NWAVE = TM / 32;                                                 // 8 / 4 waves: TM / 64 along M x 2 along N
+  constexpr int HA_PL = TM * HLD;                                                // 16 / 8 KiB per A plane and stage
+  constexpr int HN = TN, HW_PL = TN * HLD, HSTAGE = 2 * HA_PL + 2 * HW_PL;     // 64 / 48 / 32 KiB per stage
+  constexpr int HNDMA = HSTAGE / (NWAVE * 1024);                                // 1 KiB DMA instructions per wave and stage: 8 / 6 / 8
+  constexpr int NA = 2 * TM / 16;                                                // ... of which the first NA (both planes) fetch A
   constexpr int NJ = TN / 64;                                                   // 32-column blocks of a wave: 2 / 4
   __shared__ __attribute__((aligned(1024))) unsigned char stage0[HSTAGE];
   __shared__ __attribute__((aligned(1024))) unsigned char stage1[HSTAGE];
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
   // XCD-aware order: consecutive block ids land on different XCDs (round robin), so XCD x walks its own contiguous range of
   // tiles, in groups of GM row tiles x all column tiles (the A panels of a group stay in that XCD's L2 while W streams)
   constexpr int GM = 8;
-  const int tiles_m = (g.M + HM - 1) / HM, tiles_n = (g.N + HN - 1) / HN;
+  const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + HN - 1) / HN;
   const int nwg = tiles_m * tiles_n;
   int wg = blockIdx.x;
   {
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
   const int gm0 = grp * GM;
   const int gm_rows = (tiles_m - gm0 < GM) ? tiles_m - gm0 : GM;
   const int tm = gm0 + in_grp % gm_rows, tn = in_grp / gm_rows;
-  const int m0 = tm * HM, n0 = tn * HN;
+  const int m0 = tm * TM, n0 = tn * HN;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1, hi = lane >> 5, l31 = lane & 31;
@@ -137,13 +143,13 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
 #pragma unroll
   for (int j = 0; j < HNDMA; ++j) {
     const int q = wid * HNDMA + j;
-    const bool isA = q < 32;
-    const int qq = isA ? q : q - 32;
-    const int p = isA ? qq >> 4 : qq / (TN / 16), r16 = isA ? qq & 15 : qq % (TN / 16);
-    const int row = r16 * 16 + (lane >> 2) + (isA ? 0 : (tn * TN) % WTR);
+    const bool isA = q < NA;
+    const int qq = isA ? q : q - NA;
+    const int p = isA ? qq / (TM / 16) : qq / (TN / 16), r16 = isA ? qq % (TM / 16) : qq % (TN / 16);
+    const int row = r16 * 16 + (lane >> 2) + (isA ? m0 % HM : (tn * TN) % WTR);
     const int ch = (lane & 3) ^ ((lane >> 4) & 3);
     // tile-major planes: a panel is K/32 blocks of 256 rows x 32 (this workgroup's rows of each block are one contiguous run)
-    const long tile0 = (long)(isA ? tm : (tn * TN) / WTR) * (g.K / HK) * ((isA ? HM : WTR) * HK);
+    const long tile0 = (long)(isA ? m0 / HM : (tn * TN) / WTR) * (g.K / HK) * ((isA ? HM : WTR) * HK);
     src[j] = (isA ? g.A + p * g.a_plane : g.W + p * g.w_plane) + tile0 + (long)row * HK + ch * 8;
     kstep[j] = (long)(isA ? HM : WTR) * HK;
     lds_off[j] = (isA ? p * HA_PL : 2 * HA_PL + p * HW_PL) + r16 * 1024;
@@ -286,7 +292,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
       }
       if (g.out_planes) {
         // consumer plane element (m, k = n): ((m / 256) * (N / 32) + n / 32) * 256 * 32 + (m % 256) * 32 + n % 32
-        const long blk = ((long)tm * (g.N / HK) + (n0 + wn * (TN / 2) + jn * 32) / HK) * (HM * HK) + (long)(wm * 64 + i * 32 + l31) * HK;
+        const long blk = ((long)(m0 / HM) * (g.N / HK) + (n0 + wn * (TN / 2) + jn * 32) / HK) * (HM * HK) +
+                         (long)(m0 % HM + wm * 64 + i * 32 + l31) * HK;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {                            // columns 16 j .. 16 j + 15 of the K tile
           // lane hi = 0 keeps its g4 = 2j words and wants the partner's g4 = 2j words; lane hi = 1 keeps g4 = 2j + 1
@@ -310,14 +317,29 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(GemmX3Args g) {
   }
 }
 
-// tn = 0: 256 x 256 tiles when N is a multiple of 256 (every projection of the model) and they still fill the chip at least once
-// (short row sets -- one utterance -- keep the 256 x 128 tile: twice the workgroups, half the time per workgroup); 128 / 256: forced
+// Tile choice (tn = 0).  Two kernels cover every row count: 256 x 256 tiles (one 8-wave workgroup per CU; ~15 % fewer operand bytes
+// and barriers per flop) and 128 x 128 tiles (two 4-wave workgroups per CU) -- measured on MI355X over M = 384 .. 31 616 on the four
+// NAR shapes (tools/gemm_short_rows.py, profiles/r03_gemm_tiles.log) the 128 x 128 tile is never slower than 256 x 128, and which of
+// the two wins is a matter of how the tile count quantises onto 256 CUs.  Cost model in units u of one 128 x 128 tile's work on a CU
+// (fits every measured point within a few percent): a round of 256 x 256 tiles costs 4 u; the 128-row kernel runs two tiles per CU
+// in 2.3 u, a lone one in 1.3 u.  All shapes give bit-identical sums (the per-element accumulation order does not depend on the tile).
+// tn = 128 / 256 / -128: forced (256 x 128 / 256 x 256 / 128 x 128; benchmarks).
 void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s, int tn) {
-  if (tn == 0) tn = (g.N % 256 == 0 && (long)((g.M + HM - 1) / HM) * (g.N / 256) >= 256) ? 256 : 128;
-  const int tiles = ((g.M + HM - 1) / HM) * ((g.N + tn - 1) / tn);
+  int tm = HM;
+  if (tn == 0) {
+    const long mt256 = (g.M + 255) / 256, mt128 = (g.M + 127) / 128;
+    const long t128 = mt128 * ((g.N + 127) / 128);
+    const long rem = t128 % 512;
+    const double c128 = (double)(t128 / 512) * 2.3 + (rem == 0 ? 0.0 : rem <= 256 ? 1.3 : 2.3);
+    const double c256 = g.N % 256 == 0 ? (double)((mt256 * (g.N / 256) + 255) / 256) * 4.0 : 1e30;
+    if (c256 < c128) tn = 256;
+    else { tn = 128; tm = 128; }
+  } else if (tn == -128) { tn = 128; tm = 128; }
+  const int tiles = ((g.M + tm - 1) / tm) * ((g.N + tn - 1) / tn);
   if (tiles <= 0) return;
-  if (tn == 256) hipLaunchKernelGGL((gemm_f16x2_kernel<256>), dim3(tiles), dim3(512), 0, s, g);
-  else hipLaunchKernelGGL((gemm_f16x2_kernel<128>), dim3(tiles), dim3(512), 0, s, g);
+  if (tn == 256) hipLaunchKernelGGL((gemm_f16x2_kernel<256, 256>), dim3(tiles), dim3(512), 0, s, g);
+  else if (tm == 128) hipLaunchKernelGGL((gemm_f16x2_kernel<128, 128>), dim3(tiles), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_f16x2_kernel<128, 256>), dim3(tiles), dim3(512), 0, s, g);
 }
 
 }  // namespace vx
