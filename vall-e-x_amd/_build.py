@@ -52,13 +52,23 @@ def _stamp(target: str, deps, extra=()):
         f.write(_digest(deps, extra) + " " + _digest([target]))
 
 
-def build_library(force: bool = False, verbose: bool = False, dev: bool = False) -> str:
+# per-source extra flags (device code generation choices that were measured per kernel)
+EXTRA_FLAGS = {}
+
+
+def build_library(force: bool = False, verbose: bool = False, dev: bool = False, variant: str = "") -> str:
     """dev=True: a SEPARATE library with the kernels' timing probes compiled in (-DVX_DEV_PROBES), for tools/gemm_bench.py and
     tools/attn_bench.py only (tools/dev/libvallex_hip.so); the product library never contains them."""
     force = force or os.environ.get("VX_FORCE_BUILD", "") == "1"
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
     out_dir = os.path.join(os.path.dirname(HERE), "tools", "dev") if dev else CSRC
+    extra = dict(EXTRA_FLAGS)
+    if variant:      # experiment builds: tools/devx_<variant>/libvallex_hip.so, `variant` = "name:file1.hip,file2.hip:flag flag ..."
+        name, files, fl = variant.split(":", 2)
+        out_dir = os.path.join(os.path.dirname(HERE), "tools", "devx_" + name)
+        for f in files.split(","):
+            extra[f] = extra.get(f, []) + fl.split()
     os.makedirs(out_dir, exist_ok=True)
     lib = os.path.join(out_dir, "libvallex_hip.so")
     flags = FLAGS + (["-DVX_DEV_PROBES"] if dev else [])
@@ -69,17 +79,18 @@ def build_library(force: bool = False, verbose: bool = False, dev: bool = False)
         s = os.path.basename(src)
         obj = os.path.join(out_dir, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src] + hdrs, flags):
-            jobs.append(([_hipcc()] + flags + ["-c", src, "-o", obj], obj, [src] + hdrs))
+        fl = flags + extra.get(s, [])
+        if force or _stale(obj, [src] + hdrs, fl):
+            jobs.append(([_hipcc()] + fl + ["-c", src, "-o", obj], obj, [src] + hdrs, fl))
 
     def run(job):
-        cmd, target, deps = job
+        cmd, target, deps = job[:3]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
-        _stamp(target, deps, flags if target.endswith(".o") else ())
+        _stamp(target, deps, (job[3] if len(job) > 3 else flags) if target.endswith(".o") else ())
 
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
@@ -93,4 +104,5 @@ def build_library(force: bool = False, verbose: bool = False, dev: bool = False)
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True, dev="--dev" in sys.argv))
+    var = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--variant=")]
+    print(build_library(force="--force" in sys.argv, verbose=True, dev="--dev" in sys.argv, variant=var[0] if var else ""))
