@@ -16,7 +16,8 @@ for M in (384, 983, 1966, 2949, 4915, 7864, 11796, 15728, 31616):
         b = eng.bench_gemm(M, N, K, 9, 10)
         c = eng.bench_gemm(M, N, K, 8, 10)
         d = eng.bench_gemm(M, N, K, 6, 10)
-        same = "SAME" if a[1] == b[1] == c[1] else "DIFFERENT"
+        e = eng.bench_gemm(M, N, K, 10, 10)                   # 128 x 128 with two LDS stages forced (kernel 9 takes four when tiles <= 256)
+        same = "SAME" if a[1] == b[1] == c[1] == e[1] else "DIFFERENT"
         best = min((a[0], "256x128"), (b[0], "128x128"), (c[0], "256x256"))
-        print(f"M={M:5d} N={N:5d} K={K:5d}  256x128 {a[0]:7.1f}  128x128 {b[0]:7.1f}  256x256 {c[0]:7.1f}  auto {d[0]:7.1f} us   best {best[1]}  "
+        print(f"M={M:5d} N={N:5d} K={K:5d}  256x128 {a[0]:7.1f}  128x128 {b[0]:7.1f} (2 stages {e[0]:7.1f})  256x256 {c[0]:7.1f}  auto {d[0]:7.1f} us   best {best[1]}  "
               f"auto/best {d[0] / best[0]:.2f}  {same} max-diff {a[1]:.2e}", flush=True)

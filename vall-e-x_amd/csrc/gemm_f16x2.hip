@@ -103,8 +103,11 @@ void launch_absmax(const float* x, long n, unsigned* out_bits, hipStream_t s) {
 // is for row sets too short to fill the chip with 256-row tiles (one utterance: M = 983 gives 4 x N/128 workgroups on 256 CUs); its
 // A panel is the upper or lower half of a 256-row plane block.  Per output element the sequence of accumulations is the same for
 // every tile shape, so the result does not depend on which one runs.
-template <int TN, int TM>
-__global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_f16x2_kernel(GemmX3Args g) {
+// NST = LDS stages: 2, or 4 for the 128 x 128 tile when there is at most ONE workgroup per CU anyway (one utterance: the K loop of a
+// lone workgroup is a chain of LDS-DMA round trips, ~0.8 us per K tile against 0.2 us of MFMAs; with the requests three tiles ahead
+// -- counted s_waitcnt vmcnt(16 / 8 / 0) before the barrier -- the round trips overlap).
+template <int TN, int TM, int NST = 2>
+__global__ __launch_bounds__(TM * 2, (TM == 256 || NST == 4) ? 1 : 2) void gemm_f16x2_kernel(GemmX3Args g) {
   constexpr int NWAVE = TM / 32;                                                 // 8 / 4 waves: TM / 64 along M x 2 along N
   constexpr int HA_PL = TM * HLD;                                                // 16 / 8 KiB per A plane and stage
   constexpr int HN = TN, HW_PL = TN * HLD, HSTAGE = 2 * HA_PL + 2 * HW_PL;     // 64 / 48 / 32 KiB per stage
@@ -113,6 +116,8 @@ __global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_f16x2_kernel(G
   constexpr int NJ = TN / 64;                                                   // 32-column blocks of a wave: 2 / 4
   __shared__ __attribute__((aligned(1024))) unsigned char stage0[HSTAGE];
   __shared__ __attribute__((aligned(1024))) unsigned char stage1[HSTAGE];
+  __shared__ __attribute__((aligned(1024))) unsigned char stage2[NST == 4 ? HSTAGE : 16];
+  __shared__ __attribute__((aligned(1024))) unsigned char stage3[NST == 4 ? HSTAGE : 16];
 
   // XCD-aware order: consecutive block ids land on different XCDs (round robin), so XCD x walks its own contiguous range of
   // tiles, in groups of GM row tiles x all column tiles (the A panels of a group stay in that XCD's L2 while W streams)
@@ -184,6 +189,20 @@ __global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_f16x2_kernel(G
 #pragma unroll
       for (int p = 0; p < 2; ++p) a[i][p] = *reinterpret_cast<const f16x8*>(stage + p * HA_PL + a_row + i * 32 * HLD + coff);
   };
+  auto frags_asm = [&](const unsigned char* stage, int s, f16x8 (&w)[2][NJ], f16x8 (&a)[2][2]) {
+    const unsigned base = (unsigned)(unsigned long long)(lptr_t)stage + (unsigned)(((2 * s + hi) ^ sw) * 16);
+    const unsigned wa = base + (unsigned)w_row, aa = base + (unsigned)a_row;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int jn = 0; jn < NJ; ++jn)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w[p][jn]) : "v"(wa), "n"(2 * HA_PL + p * HW_PL + jn * 32 * HLD));
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[i][p]) : "v"(aa), "n"(p * HA_PL + i * 32 * HLD));
+  };
   // One k16 step: transposed product (A operand = W rows); the three terms of a block go into the same accumulator, small ones
   // first -- tail.head, head.tail, head.head -- and the blocks of the wave take turns, so no MFMA waits for the one before it
   // on the same accumulator.  SPREAD (256-wide tile): DMA instruction 4 s + 0..3 of the next stage behind MFMAs 3, 9, 15, 21.
@@ -227,6 +246,43 @@ __global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_f16x2_kernel(G
   };
 
   const int nk = g.K / HK;
+  if constexpr (NST == 4) {
+    static_assert(TN == 128 && TM == 128, "the four-stage ring is the short-row-set kernel");
+    // tile t lives in stage t % 4; its requests are issued three tiles ahead, right behind the barrier of tile t - 3 (every wave
+    // is past its reads of tile t - 4, the previous tenant of the stage).  Before the barrier of tile t a wave waits for ITS OWN
+    // requests of tile t only: the (up to two) younger groups of 8 stay in flight.
+    unsigned char* const st[4] = {stage0, stage1, stage2, stage3};
+    dma(stage0, 0);
+    if (nk > 1) dma(stage1, 1);
+    if (nk > 2) dma(stage2, 2);
+    auto step = [&](int t, int u) {
+      const int younger = nk - 1 - t;                                       // request groups issued after tile t's: min(2, younger)
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // bare barrier: __syncthreads() carries a workgroup-scope fence, which the compiler implements as s_waitcnt vmcnt(0) -- it
+      // would wait for the younger request groups as well.  What has to be ordered here is LDS traffic inside one CU: this wave's
+      // fragment reads of the previous tile are complete (their data fed its MFMAs), its requests of tile t have landed.
+      __builtin_amdgcn_s_barrier();
+      if (t + 3 < nk) dma(st[(u + 3) & 3], t + 3);
+      // fragment reads as inline asm: for a C++ LDS load the compiler's LDS-DMA tracking cannot tell the stages apart and inserts
+      // s_waitcnt vmcnt(0) right behind the requests just issued; the hazards are ordered by the counted wait + barrier above
+      frags_asm(st[u], 0, w0, a0);
+      frags_asm(st[u], 1, w1, a1);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0[0][0]), "+v"(w0[0][1]), "+v"(w0[1][0]), "+v"(w0[1][1]), "+v"(a0[0][0]), "+v"(a0[0][1]),
+                   "+v"(a0[1][0]), "+v"(a0[1][1]));
+      asm volatile("" : "+v"(w1[0][0]), "+v"(w1[0][1]), "+v"(w1[1][0]), "+v"(w1[1][1]), "+v"(a1[0][0]), "+v"(a1[0][1]), "+v"(a1[1][0]),
+                   "+v"(a1[1][1]));
+      kstep16(w0, a0, nullptr, 0, false, 0);
+      kstep16(w1, a1, nullptr, 0, false, 1);
+    };
+    for (int kt = 0; kt < nk; kt += 4) {
+      step(kt, 0);
+      if (kt + 1 < nk) step(kt + 1, 1);
+      if (kt + 2 < nk) step(kt + 2, 2);
+      if (kt + 3 < nk) step(kt + 3, 3);
+    }
+  } else {
   dma(stage0, 0);
   for (int kt = 0; kt < nk; kt += 2) {
     rendezvous();
@@ -235,6 +291,7 @@ __global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_f16x2_kernel(G
       rendezvous();
       ktile(stage1, stage0, kt + 2, kt + 2 < nk);
     }
+  }
   }
   // epilogue: C = accumulator * 2^-(sa + sw) (+ bias, activation, residual as in the bf16x3 kernels).
   // With g.out_planes set, the result is NOT written as fp32 rows: it is split on the spot into the f16x2 planes of the NEXT
@@ -334,10 +391,14 @@ void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s, int tn) {
     const double c256 = g.N % 256 == 0 ? (double)((mt256 * (g.N / 256) + 255) / 256) * 4.0 : 1e30;
     if (c256 < c128) tn = 256;
     else { tn = 128; tm = 128; }
-  } else if (tn == -128) { tn = 128; tm = 128; }
+  } else if (tn == -128 || tn == -129) { tm = tn == -129 ? 129 : 128; tn = 128; }      // -129: 128 x 128 tiles, two stages forced
+  const bool two_stage = tm == 129;
+  if (two_stage) tm = 128;
   const int tiles = ((g.M + tm - 1) / tm) * ((g.N + tn - 1) / tn);
   if (tiles <= 0) return;
   if (tn == 256) hipLaunchKernelGGL((gemm_f16x2_kernel<256, 256>), dim3(tiles), dim3(512), 0, s, g);
+  else if (tm == 128 && tiles <= 256 && !two_stage)      // at most one workgroup per CU: four LDS stages, requests three K tiles ahead
+    hipLaunchKernelGGL((gemm_f16x2_kernel<128, 128, 4>), dim3(tiles), dim3(256), 0, s, g);
   else if (tm == 128) hipLaunchKernelGGL((gemm_f16x2_kernel<128, 128>), dim3(tiles), dim3(256), 0, s, g);
   else hipLaunchKernelGGL((gemm_f16x2_kernel<128, 256>), dim3(tiles), dim3(512), 0, s, g);
 }
