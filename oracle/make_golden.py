@@ -121,6 +121,19 @@ TRAINED_CASES = {
     "nl12_trained_zh_topk10": dict(num_layers=12, seed=0, eos_gain=0.0, trained=True, preset="paimon", n_text=100, lang="zh",
                                    top_k=10, force_eos_at=600, useed=4567, full=True, text_seed=7),
 }
+# The Gradio UI's own call (launch-ui.py:285-295): unfiltered multinomial (top_k=-100, temperature 1), best_of=5 beams ranked by
+# sum(logp) / len (models/vallex.py:583-594), here on the full 12-layer model with trained-like weights whose EOS logit is live
+# (eos_gain 1.85): four beams end by themselves after 9, 9, 8 and 13 frames, the fifth runs into the forced EOS at 120 (which only
+# bounds the fixture); finished beams keep emitting EOS while the others go on (:572-573).  The best beam is a 9-frame one;
+# `_worst` (return_worst=True) returns the 120-frame one.  The uniforms seed was chosen among twelve for the largest decision margin
+# of the inverse-CDF draws (min over all beams and steps of |cdf - u| = 9.2e-4; seeds with 1e-6 exist and pin nothing).
+UI_CASES = {
+    "nl12_ui_bestof5_ja": dict(num_layers=12, seed=0, eos_gain=1.85, trained=True, preset="cafe", n_text=40, lang="ja", top_k=-100,
+                               temperature=1.0, best_of=5, force_eos_at=120, useed=8643, text_seed=11),
+    "nl12_ui_bestof5_ja_worst": dict(num_layers=12, seed=0, eos_gain=1.85, trained=True, preset="cafe", n_text=40, lang="ja",
+                                     top_k=-100, temperature=1.0, best_of=5, force_eos_at=120, useed=8643, text_seed=11,
+                                     return_worst=True),
+}
 LONG_CASES = {
     "nl12_cap1024_en": dict(num_layers=12, seed=0, eos_gain=0.0, preset="librispeech_1", n_text=6, lang="en", top_k=1,
                             force_eos_at=None, useed=None, full=True, text_seed=8),
@@ -172,6 +185,11 @@ CONTINUAL_CASES = {
     "nl2_continual_long": dict(num_layers=2, seed=7, eos_gain=1.0, n_text=9, frames=470),     # prefix_len = 225 (3 s cap)
 }
 
+# the same on the full model with trained-like weights (tests/test_gpu_trained_like.py; the oracle side runs with VX_SLOW=1)
+CONTINUAL12_CASES = {
+    "nl12_continual_trained": dict(num_layers=12, seed=0, eos_gain=0.0, trained=True, n_text=60, frames=450),   # prefix_len = 225
+}
+
 CODE2LANG = {0: "zh", 1: "ja", 2: "en"}      # macros.py:15-19 via utils/generation.py:114-115
 
 
@@ -198,7 +216,7 @@ def case_inputs(c):
 def case_state_dict(c):
     """the weights of a case (tests and the generator build them the same way)"""
     if c.get("trained"):
-        return synth.trained_like_state_dict(c["num_layers"], c["seed"])
+        return synth.trained_like_state_dict(c["num_layers"], c["seed"], eos_gain=c["eos_gain"])
     sd = synth.vallex_state_dict(c["num_layers"], c["seed"], c["eos_gain"], c.get("attn_gain", 1.0))
     if c.get("range_kind"):
         sd = synth.out_of_range_state_dict(sd, c["num_layers"], c["range_kind"])
@@ -208,7 +226,7 @@ def case_state_dict(c):
 def all_cases():
     """every named single-call case (name -> dict); RANGE_CASES are their base case + `range_kind`"""
     out = {}
-    for grp in (CASES, SHARP_CASES, EDGE_CASES, FULL_CASES, TRAINED_CASES, LONG_CASES):
+    for grp in (CASES, SHARP_CASES, EDGE_CASES, FULL_CASES, TRAINED_CASES, LONG_CASES, UI_CASES):
         out.update(grp)
     for name, (base, kind) in RANGE_CASES.items():
         out[name] = dict(out[base], range_kind=kind)
@@ -325,7 +343,7 @@ def run_reference_continual(c):
 
     m = VALLE(1024, 16, c["num_layers"], norm_first=True, add_prenet=False, prefix_mode=1,
               share_embedding=True, nar_scale_factor=1.0, prepend_bos=True, num_quantizers=8).eval()
-    sd = synth.vallex_state_dict(c["num_layers"], c["seed"], c["eos_gain"])
+    sd = case_state_dict(c)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
     text, y = continual_inputs(c)
     with torch.no_grad():
@@ -351,8 +369,8 @@ def main(only=None):
     if only and "preset_shapes" in only:
         make_preset_shapes()
         return
-    for name, c in CONTINUAL_CASES.items():
-        if only and name not in only:
+    for name, c in list(CONTINUAL_CASES.items()) + list(CONTINUAL12_CASES.items()):
+        if (only and name not in only) or (not only and name in CONTINUAL12_CASES):
             continue
         out = run_reference_continual(c)
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
@@ -378,7 +396,7 @@ def main(only=None):
         print(name, "live reference == golden of", base, "| max |logit diff|", float(np.abs(out["ar_logits"] - gold["ar_logits"]).max()),
               flush=True)
     for name, c in (list(CASES.items()) + list(SHARP_CASES.items()) + list(EDGE_CASES.items()) + list(FULL_CASES.items())
-                    + list(TRAINED_CASES.items()) + list(LONG_CASES.items())):
+                    + list(TRAINED_CASES.items()) + list(LONG_CASES.items()) + list(UI_CASES.items())):
         if only and name not in only:
             continue
         if c.get("full") and not only and os.path.exists(os.path.join(GOLD, name + ".npz")):

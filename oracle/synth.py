@@ -136,7 +136,8 @@ def _layer_prefixes(num_layers):
 
 
 def trained_like_state_dict(num_layers: int = 12, seed: int = 0, logit_gain: float = 6.0,
-                            emb_offset: float = 2.0, massive_bias: float = 4.0, ln_hi: float = 4.0) -> "OrderedDict[str, np.ndarray]":
+                            emb_offset: float = 2.0, massive_bias: float = 4.0, ln_hi: float = 4.0,
+                            eos_gain: float = 0.0) -> "OrderedDict[str, np.ndarray]":
     """A state-dict with the STATISTICS of a trained checkpoint (utils/generation.py:79-83 loads one; it is not available
     offline), derived from `vallex_state_dict(num_layers, seed, eos_gain=0)` by a second, independent RNG stream -- the base
     stream and with it every other fixture stays what it was.  What the default init lacks and this adds:
@@ -150,8 +151,9 @@ def trained_like_state_dict(num_layers: int = 12, seed: int = 0, logit_gain: flo
       * decisive AR logits: ar_predict_layer x logit_gain (logit std ~9, median top-2 gap ~2 >> fp32 noise).
     (Stronger settings -- offset 12, bias 20, gain 16 -- collapse greedy decoding into 2-cycles of ~10 distinct ids; these keep
     the statistics and some variety.)
-    The EOS row stays zero (eos_gain 0), so runs end at the forced step only."""
-    sd = vallex_state_dict(num_layers, seed, eos_gain=0.0)
+    The EOS row stays zero by default (eos_gain 0), so runs end at the forced step only; eos_gain > 0 gives the EOS logit the
+    statistics of the other 1024 (sampled runs then end by themselves, at a different step per beam)."""
+    sd = vallex_state_dict(num_layers, seed, eos_gain=eos_gain)
     rng = np.random.default_rng(770_000 + seed)
     d = D_MODEL
     keep_rms = np.float32(math.exp(-0.45 * 0.45))            # E[exp(2 * 0.45 z)] ** -0.5

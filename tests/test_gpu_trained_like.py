@@ -7,7 +7,8 @@ stay inside the fp16 range: the format's margin, not the fallback, carries them)
 import numpy as np
 import pytest
 
-from oracle.make_golden import FULL_LOGIT_EVERY, TRAINED_CASES
+from oracle import synth
+from oracle.make_golden import CONTINUAL12_CASES, FULL_LOGIT_EVERY, TRAINED_CASES, UI_CASES, case_inputs, continual_inputs
 from tests._util import assert_codes, case_model, golden, inputs_row, nar_logit_error, teacher_forced_logit_error
 
 pytestmark = pytest.mark.gpu
@@ -53,7 +54,6 @@ def test_trained_like_logits(arith):
 def test_trained_like_row_inside_a_batch(name, nrows, slot):
     """the same golden rows through the other two decode chains: 32 rows (one context split, out_proj fused into dec_attn, 16 head
     slabs) and 8 rows (context-split dec_attn + combine + separate out_proj) -- alone they take the small-batch chain"""
-    from oracle import synth
     c = TRAINED_CASES[name]
     g = golden(name)
     row, us = inputs_row(c)
@@ -75,3 +75,36 @@ def test_trained_like_row_inside_a_batch(name, nrows, slot):
                              force_eos_at=c["force_eos_at"])
     assert m.engine.last_fallbacks()["lifetime"] == 0
     assert_codes(f"{name} as row {slot} of {nrows}", outs[slot], g)
+
+
+@pytest.mark.parametrize("name", sorted(UI_CASES))
+def test_ui_call_best_of_5_matches_the_live_reference(name):
+    """launch-ui.py:285-295: top_k=-100 (unfiltered multinomial), temperature 1, best_of=5, on 12 trained-like layers with a live
+    EOS logit -- four beams end by themselves at different steps, one runs on; the reference's pick (best, and the worst with
+    return_worst) must come back bit for bit.  Five beams decode on the context-split chain (5..31 rows)."""
+    c = UI_CASES[name]
+    a, t, text, pl, langs = case_inputs(c)
+    m = case_model(c, max_new=128, max_prompt=700, max_text=256, max_batch=8)
+    us = synth.uniforms(4096, c["best_of"], c["useed"])
+    out = m.inference(text, np.array([text.shape[-1]]), a, t.shape[-1], top_k=c["top_k"], temperature=c["temperature"],
+                      prompt_language=pl, text_language=langs, uniforms=us, force_eos_at=c["force_eos_at"], best_of=c["best_of"],
+                      return_worst=c.get("return_worst", False))
+    g = golden(name)["codes"]
+    assert tuple(out.shape) == g.shape, (tuple(out.shape), g.shape)
+    np.testing.assert_array_equal(out.numpy(), g)
+    assert m.engine.last_fallbacks()["lifetime"] == 0
+
+
+
+@pytest.mark.parametrize("arith", ["f16x2", "f32"])
+def test_continual_on_trained_like_weights(arith):
+    """`VALLE.continual` (models/vallex.py:688-787) on the 12 trained-like layers: 225 given + 225 continued frames, the seven NAR
+    stages only; the live reference's ids (smallest arg-max margin 2.8e-2 on logits to |220|)"""
+    name = "nl12_continual_trained"
+    c = CONTINUAL12_CASES[name]
+    m = case_model(c, arith=arith, **KW)
+    text, y = continual_inputs(c)
+    out = m.continual(text, np.array([text.shape[-1]]), y)
+    out = out.numpy() if hasattr(out, "numpy") else out
+    np.testing.assert_array_equal(out, golden(name)["codes"])
+    assert m.engine.last_fallbacks()["nar"] == 0

@@ -70,6 +70,17 @@ def test_oracle_continual_matches_reference(name):
     np.testing.assert_array_equal(out[0, :, 0], y[0, prefix_len:, 0])      # first codebook is passed through
 
 
+def test_oracle_continual_matches_reference_12_trained_like_layers():
+    """the same on the full model with trained-like weights (225 given + 225 continued frames); smallest arg-max margin of the
+    seven stages 2.8e-2, logits to |220|"""
+    from oracle.make_golden import CONTINUAL12_CASES, case_state_dict
+    name = "nl12_continual_trained"
+    c = CONTINUAL12_CASES[name]
+    text, y = continual_inputs(c)
+    out = VallexOracle(case_state_dict(c), c["num_layers"]).continual(text, np.array([text.shape[-1]]), y)
+    np.testing.assert_array_equal(out, np.load(os.path.join(GOLD, name + ".npz"))["codes"])
+
+
 @pytest.mark.parametrize("name", sorted(SHARP_CASES))
 def test_oracle_matches_reference_tokens_sharp_attention(name):
     """attn_gain 3 weights (peaky, trained-looking attention): this test bed reacts to K/V precision and to the score
@@ -226,6 +237,22 @@ def test_oracle_matches_reference_sliding_window_chain():
     np.testing.assert_array_equal(_run_case(c, inputs=chain_second(c, c1), useed=c["useed2"]), g["codes"])
 
 
+@pytest.mark.skipif(not SLOW, reason="five 12-layer beams on the CPU oracle (~30 s); VX_SLOW=1 (the GPU suite runs it)")
+def test_oracle_matches_reference_ui_call_best_of_5():
+    """launch-ui.py:285-295 on 12 trained-like layers: the best and the worst of five unfiltered-multinomial beams"""
+    from oracle.make_golden import UI_CASES, case_state_dict
+    c = UI_CASES["nl12_ui_bestof5_ja"]
+    orc = VallexOracle(case_state_dict(c), c["num_layers"])
+    a, t, text, pl, langs = case_inputs(c)
+    us = synth.uniforms(4096, c["best_of"], c["useed"])
+    for name, worst in (("nl12_ui_bestof5_ja", False), ("nl12_ui_bestof5_ja_worst", True)):
+        taps = {}
+        codes = orc.inference(text, np.array([text.shape[-1]]), a, t.shape[-1], top_k=c["top_k"], temperature=c["temperature"],
+                              prompt_language=pl, text_language=langs, uniforms=us, force_eos_at=c["force_eos_at"], taps=taps,
+                              best_of=c["best_of"], return_worst=worst)
+        np.testing.assert_array_equal(codes, np.load(os.path.join(GOLD, name + ".npz"))["codes"], err_msg=name)
+
+
 def test_round3_fixture_shapes():
     """what the committed fixtures hold (cheap; the content is compared on the GPU and, with VX_SLOW=1, by the oracle)"""
     from oracle.make_golden import CHAIN_CASES, CHAIN_FRAMES, LONG_CASES, TRAINED_CASES, chain_second
@@ -244,3 +271,6 @@ def test_round3_fixture_shapes():
     for n in TRAINED_CASES:
         g = np.load(os.path.join(GOLD, n + ".npz"))
         assert g["codes"].shape == (1, 600, 8) and float(np.abs(g["ar_logits"]).max()) > 20.0      # decisive logits
+    # the UI call: the best beam ended by itself, the worst ran to the forced end; same weights, same draws
+    best, worst = (np.load(os.path.join(GOLD, n + ".npz"))["codes"] for n in ("nl12_ui_bestof5_ja", "nl12_ui_bestof5_ja_worst"))
+    assert best.shape == (1, 9, 8) and worst.shape == (1, 120, 8) and int(max(best.max(), worst.max())) < 1024
