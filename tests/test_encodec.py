@@ -204,8 +204,10 @@ def test_make_prompt_writes_a_reference_format_preset(tmp_path):
         assert out.shape == (8 * 320,) and np.isfinite(out).all()
         with pytest.raises(ValueError, match="too long"):
             PM.make_prompt("long", (np.zeros((1, 24000 * 16), np.float32), 24000), transcript="x", save_dir=str(tmp_path))
-        with pytest.raises(NotImplementedError):
-            PM.make_prompt("sr", (np.zeros((1, 16000), np.float32), 16000), transcript="x", save_dir=str(tmp_path))
+        # another sample rate is resampled to 24 kHz first (data/tokenizer.py:105): 16000 samples at 16 kHz -> 24000 -> 75 frames
+        d3 = np.load(PM.make_prompt("sr", (0.1 * rng.standard_normal((1, 16000)).astype(np.float32), 16000), transcript="x",
+                                    save_dir=str(tmp_path)))
+        assert d3["audio_tokens"].shape == (1, 75, 8)
     finally:
         G.language_detector = None
         G.text_tokenizer = None

@@ -4,14 +4,18 @@
 implementation.  The audio side (EnCodec SEANet encoder + RVQ, 6 kbps) runs in libvallex_hip.so (`vx_encodec_encode`).
 
 What is NOT here (third-party CPU code outside the hot path): Whisper transcription (pass `transcript=`), the G2P /
-BPE tokenizer and langid (same pluggable hooks as `utils.generation`), torchaudio's resampler (audio must already be 24 kHz; mono or
-stereo -- stereo is averaged like the reference does, utils/prompt_making.py:63-64).
+BPE tokenizer and langid (same pluggable hooks as `utils.generation`).  Audio at another sample rate is resampled to 24 kHz like the
+reference does (data/tokenizer.py:105 `convert_audio` = `torchaudio.transforms.Resample(sr, 24000)`): `resample_sinc_hann` below restates
+torchaudio's published default (Hann-windowed sinc, lowpass_filter_width 6, rolloff 0.99) -- torchaudio is not installed here, so this
+one piece is NOT pinned to the package; assign `resampler = lambda wav, sr, target_sr: ...` to plug in the real one.  Stereo is averaged
+like the reference does (utils/prompt_making.py:63-64).
 """
 from __future__ import annotations
 
 import logging
+import math
 import os
-from typing import Optional, Tuple, Union
+from typing import Callable, Optional, Tuple, Union
 
 import numpy as np
 
@@ -21,6 +25,37 @@ from . import generation as G
 
 codec: Optional[AudioTokenizer] = None        # module global like the reference's (utils/prompt_making.py:27)
 CUSTOMS_DIR = "./customs/"
+resampler: Optional[Callable[[np.ndarray, int, int], np.ndarray]] = None      # (wav (C, L), sr, target_sr) -> (C, L'); None = built-in
+
+
+def resample_sinc_hann(wav: np.ndarray, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6,
+                       rolloff: float = 0.99) -> np.ndarray:
+    """Band-limited resampling of (C, L) fp32 audio: the algorithm torchaudio documents for `transforms.Resample` with its defaults
+    (resampling_method "sinc_interp_hann").  With o, n = the two rates over their gcd: n phase kernels of 2*width + o taps,
+    k_i[j] = sinc(t) * cos^2(pi t / (2 lpw)) * base / o with t = clamp((-i / n + (j - width) / o) * base, +-lpw), base =
+    min(o, n) * rolloff, width = ceil(lpw * o / base) (built in fp64, applied in fp32); the zero-padded signal is correlated at
+    stride o, the n phases interleave to the output, cut to ceil(n * L / o) samples."""
+    import torch
+    import torch.nn.functional as F
+    wav = np.asarray(wav, np.float32)
+    g = math.gcd(int(orig_freq), int(new_freq))
+    o, n = int(orig_freq) // g, int(new_freq) // g
+    if o == n:
+        return wav
+    base = min(o, n) * rolloff
+    width = math.ceil(lowpass_filter_width * o / base)
+    idx = torch.arange(-width, width + o, dtype=torch.float64)[None, None] / o
+    t = (torch.arange(0, -n, -1, dtype=torch.float64)[:, None, None] / n + idx) * base
+    t = t.clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernels = (torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base / o)).to(torch.float32)    # (n, 1, 2*width + o)
+    x = torch.from_numpy(np.ascontiguousarray(wav.reshape(-1, wav.shape[-1])))
+    length = x.shape[-1]
+    x = F.pad(x, (width, width + o))
+    y = F.conv1d(x[:, None], kernels, stride=o).transpose(1, 2).reshape(x.shape[0], -1)
+    y = y[:, : math.ceil(n * length / o)]
+    return y.reshape(wav.shape[:-1] + (y.shape[-1],)).numpy()
 
 
 def _load_wav(path: str) -> Tuple[np.ndarray, int]:
@@ -41,11 +76,10 @@ def tokenize_audio(tokenizer: AudioTokenizer, audio: Union[str, Tuple[np.ndarray
     wav = np.asarray(wav.detach().cpu().numpy() if hasattr(wav, "detach") else wav, np.float32)
     if wav.ndim == 1:
         wav = wav[None]
-    if sr != tokenizer.sample_rate:
-        raise NotImplementedError(f"audio is {sr} Hz: resample to {tokenizer.sample_rate} Hz first (the reference uses "
-                                  "torchaudio's convert_audio, data/tokenizer.py:105; no resampler is bundled here)")
-    if wav.shape[0] > 1:                                          # convert_audio(..., target_channels=1): channel mean
+    if wav.shape[0] > 1:                                          # convert_audio(..., target_channels=1): channel mean, then resample
         wav = wav.mean(0, keepdims=True)
+    if sr != tokenizer.sample_rate:
+        wav = np.asarray((resampler or resample_sinc_hann)(wav, int(sr), tokenizer.sample_rate), np.float32)
     return tokenizer.encode(wav[None])                            # (1, 1, L)
 
 
