@@ -204,10 +204,13 @@ def test_make_prompt_writes_a_reference_format_preset(tmp_path):
         assert out.shape == (8 * 320,) and np.isfinite(out).all()
         with pytest.raises(ValueError, match="too long"):
             PM.make_prompt("long", (np.zeros((1, 24000 * 16), np.float32), 24000), transcript="x", save_dir=str(tmp_path))
-        # another sample rate is resampled to 24 kHz first (data/tokenizer.py:105): 16000 samples at 16 kHz -> 24000 -> 75 frames
-        d3 = np.load(PM.make_prompt("sr", (0.1 * rng.standard_normal((1, 16000)).astype(np.float32), 16000), transcript="x",
-                                    save_dir=str(tmp_path)))
-        assert d3["audio_tokens"].shape == (1, 75, 8)
+        # another sample rate is resampled to 24 kHz first (data/tokenizer.py:105): 8000 samples at 16 kHz -> 12000 -> 38 frames
+        # (this engine's arena holds max_new = 64 frames)
+        w16 = (0.1 * rng.standard_normal((1, 8000))).astype(np.float32)
+        d3 = np.load(PM.make_prompt("sr", (w16, 16000), transcript="x", save_dir=str(tmp_path)))
+        assert d3["audio_tokens"].shape == (1, 38, 8)
+        direct = np.asarray(tok.encode(PM.resample_sinc_hann(w16, 16000, 24000)[None])[0][0])
+        np.testing.assert_array_equal(np.transpose(direct, (0, 2, 1)), d3["audio_tokens"])
     finally:
         G.language_detector = None
         G.text_tokenizer = None
