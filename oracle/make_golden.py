@@ -86,6 +86,14 @@ EDGE_CASES = {
                         force_eos_at=5, useed=None),
 }
 
+# The largest enrolment the reference accepts: make_prompt refuses audio over 15 s (utils/prompt_making.py:60-61) -> 1125 frames; with the
+# longest preset transcript (160 ids) + 96 text ids: S = 256, prefill over 256 + 1 + 1125 = 1382 positions, NAR stages over 1421 rows --
+# the longest single sequence of any fixture (2 layers keep it cheap; the kernels do not know the layer count).
+MAX_CASES = {
+    "nl2_max_prompt": dict(num_layers=2, seed=4, eos_gain=1.0, synth_prompt=(1125, 160), prompt_lang="en", n_text=96, lang="zh",
+                           top_k=10, force_eos_at=40, useed=99),
+}
+
 # BASELINE C1/C2/C3 shape at FULL length: 12 layers, preset prompt + 100 phoneme ids, EOS forced at
 # 600 frames (8.0 s) => Ltot = S + Tp + 600 ~ 983 for librispeech_1.  Weights = the bench weights (seed 0, eos_gain 0: the EOS
 # logit is exactly 0, never the arg-max and never inside the top-10, so no run ends early).  All six share ONE weight set so
@@ -226,7 +234,7 @@ def case_state_dict(c):
 def all_cases():
     """every named single-call case (name -> dict); RANGE_CASES are their base case + `range_kind`"""
     out = {}
-    for grp in (CASES, SHARP_CASES, EDGE_CASES, FULL_CASES, TRAINED_CASES, LONG_CASES, UI_CASES):
+    for grp in (CASES, SHARP_CASES, EDGE_CASES, MAX_CASES, FULL_CASES, TRAINED_CASES, LONG_CASES, UI_CASES):
         out.update(grp)
     for name, (base, kind) in RANGE_CASES.items():
         out[name] = dict(out[base], range_kind=kind)
@@ -395,7 +403,8 @@ def main(only=None):
         assert np.array_equal(out["codes"], gold["codes"]), (name, "live reference differs from the base golden")
         print(name, "live reference == golden of", base, "| max |logit diff|", float(np.abs(out["ar_logits"] - gold["ar_logits"]).max()),
               flush=True)
-    for name, c in (list(CASES.items()) + list(SHARP_CASES.items()) + list(EDGE_CASES.items()) + list(FULL_CASES.items())
+    for name, c in (list(CASES.items()) + list(SHARP_CASES.items()) + list(EDGE_CASES.items()) + list(MAX_CASES.items())
+                    + list(FULL_CASES.items())
                     + list(TRAINED_CASES.items()) + list(LONG_CASES.items()) + list(UI_CASES.items())):
         if only and name not in only:
             continue

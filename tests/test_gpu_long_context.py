@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from oracle import synth
-from oracle.make_golden import CHAIN_CASES, EDGE_CASES, FULL_LOGIT_EVERY, LONG_CASES, chain_second
+from oracle.make_golden import CHAIN_CASES, EDGE_CASES, FULL_LOGIT_EVERY, LONG_CASES, MAX_CASES, chain_second
 from tests._util import assert_codes, case_model, golden, inputs_row, nar_logit_error, teacher_forced_logit_error
 
 pytestmark = pytest.mark.gpu
@@ -126,3 +126,24 @@ def test_edge_fixtures_from_the_live_reference(name):
         m2 = case_model(c, debug_taps=True, max_new=64, max_prompt=400, max_text=128, max_batch=4)
         m2.engine.ar_prefill(m2.make_batch([row]))
         np.testing.assert_allclose(m2.engine.ar_logits()[0], g["ar_logits"][0], atol=3e-4, rtol=0)
+
+
+def test_largest_enrolment_alone_and_in_a_batch():
+    """the longest prompt the reference enrols (15 s = 1125 frames, utils/prompt_making.py:60-61) with 256 text ids: causal prefill
+    over 1382 positions, decode contexts to 1422, the seven NAR stages over 1421 rows -- the longest single sequence of any fixture
+    (2 layers); the live reference's ids alone (small-batch chain) and as row 3 of 5 (context-split chain)"""
+    name = "nl2_max_prompt"
+    c = MAX_CASES[name]
+    g = golden(name)
+    row, us = inputs_row(c)
+    assert len(row["text"]) == 256 and row["prompt"].shape == (1125, 8)
+    m = case_model(c, max_new=64, max_prompt=1152, max_text=256, max_batch=8)
+    out = m.inference_batch([row], top_k=c["top_k"], uniforms=us[:, None], force_eos_at=c["force_eos_at"])[0]
+    assert_codes(name, out, g)
+    rows = _filler_rows(4, 90, 300, 71_000, "ja")
+    rows.insert(3, row)
+    cols = [synth.uniforms(4096, 1, 72_000 + i)[:, 0] for i in range(5)]
+    cols[3] = us
+    outs = m.inference_batch(rows, top_k=c["top_k"], uniforms=np.stack(cols, axis=1), force_eos_at=c["force_eos_at"])
+    assert_codes(f"{name} as row 3 of 5", outs[3], g)
+    assert m.engine.last_fallbacks()["lifetime"] == 0

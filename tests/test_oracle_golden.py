@@ -81,6 +81,20 @@ def test_oracle_continual_matches_reference_12_trained_like_layers():
     np.testing.assert_array_equal(out, np.load(os.path.join(GOLD, name + ".npz"))["codes"])
 
 
+def test_oracle_matches_reference_at_the_largest_enrolment():
+    """15 s of prompt (1125 frames, utils/prompt_making.py:60-61) + 256 text ids: prefill over 1382 positions, NAR over 1421 rows"""
+    from oracle.make_golden import MAX_CASES
+    c = MAX_CASES["nl2_max_prompt"]
+    g = np.load(os.path.join(GOLD, "nl2_max_prompt.npz"))
+    a, t, text, pl, langs = case_inputs(c)
+    assert a.shape == (1, 1125, 8) and text.shape == (1, 256)
+    taps = {}
+    codes = _run_case(c, taps=taps)
+    np.testing.assert_array_equal(codes, g["codes"])
+    ar = np.stack([l.numpy() for l in taps["ar_logits"][: g["ar_logits"].shape[0]]])
+    np.testing.assert_allclose(ar, g["ar_logits"], atol=2e-4, rtol=0)
+
+
 @pytest.mark.parametrize("name", sorted(SHARP_CASES))
 def test_oracle_matches_reference_tokens_sharp_attention(name):
     """attn_gain 3 weights (peaky, trained-looking attention): this test bed reacts to K/V precision and to the score
