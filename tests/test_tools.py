@@ -34,3 +34,18 @@ def test_experiment_patches_still_apply():
     for p in patches:
         r = subprocess.run(["git", "apply", "--check", p], cwd=ROOT, capture_output=True, text=True)
         assert r.returncode == 0, (os.path.basename(p), r.stderr)
+
+
+def test_committed_resource_report_shows_no_spills():
+    """profiles/rNN_isa_resources.txt (tools/isa_resources.sh, compiler's own figures): every kernel of the library, none with
+    scratch, and the occupancies the design counts on"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_isa_resources.txt")))
+    assert files
+    rows = {}
+    for line in open(files[-1]).read().splitlines()[1:]:
+        name, rest = line[:58].strip(), line[58:].split()
+        rows[name] = dict(zip(("vgpr", "agpr", "scratch", "lds", "occ"), (int(v) for v in rest)))
+    assert len(rows) >= 50
+    assert all(r["scratch"] == 0 for r in rows.values()), [n for n, r in rows.items() if r["scratch"]]
+    assert rows["gemm_f16x2_kernel<256, 256, 2> (gemm_f16x2)"]["lds"] == 131072          # one 8-wave workgroup per CU
+    assert rows["attn_full_h2_kernel (attn_full_h2)"]["occ"] == 2 and rows["dec_attn_kernel<true, 4> (decode)"]["occ"] == 4
