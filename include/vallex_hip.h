@@ -154,25 +154,6 @@ int vx_nar(vx_ctx* ctx, const vx_batch* b, const int32_t* codes0, int32_t codes0
 /* copy a named debug buffer to the host (needs cfg.debug_taps); returns the number of floats copied or < 0 */
 int64_t vx_read_tap(vx_ctx* ctx, const char* name, float* dst, int64_t max_floats);
 
-/* ---- measurement ------------------------------------------------------------------------------------------
- * HIP-event timing of kernel classes on the context's own stream (bench.py roofline leg).
- * which: 0 = dec_attn (KV streaming), 1 = skinny GEMMs, 2 = transformer projections (full-sequence GEMMs), 3 = full-seq
- * attention, 4 = the fp32 GEMMs of the Vocos / EnCodec heads.
- * vx_prof_enable(1) makes the AR step run un-graphed with an event pair around each launch of every class. */
-int vx_prof_enable(vx_ctx* ctx, int32_t on);
-int vx_prof_get(vx_ctx* ctx, int32_t which, double* total_ms, int64_t* launches, double* algo_bytes);
-int vx_prof_reset(vx_ctx* ctx);
-/* GPU-bound micro-replay of one decode kernel on the state the last AR run left behind: `reps` back-to-back launches
- * between ONE event pair (eager per-launch events pick up host launch gaps; events recorded inside a hipGraph cannot be
- * timed on ROCm 7.2).  which 0: dec_attn with every row at context prefill_len + gen_offset; which 1: the four
- * weight-streaming GEMMs of a layer.  avg_us = per launch; algo_bytes = algorithmic bytes per launch. */
-int vx_bench_kernel(vx_ctx* ctx, int32_t which, int32_t reps, int32_t gen_offset, double* avg_us, double* algo_bytes);
-/* kernel-development aid: time one full-sequence GEMM kernel (0 fp32 MFMA, 1 bf16x3) on scratch data and
- * report its max abs difference to the fp32-MFMA kernel.  Not used by the product path. */
-int vx_bench_gemm(vx_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t kernel, int32_t reps, double* avg_us,
-                  double* max_abs_diff);
-int vx_bench_attn(vx_ctx* ctx, int32_t batch, int32_t len, int32_t causal, int32_t variant, int32_t reps, double* avg_us,
-                  double* max_diff);
 /* counters of the last vx_infer: AR steps run, generated frames, AR / NAR wall milliseconds (stream-synchronised) */
 int vx_last_stats(vx_ctx* ctx, int64_t* ar_steps, int64_t* frames, double* ar_ms, double* nar_ms);
 

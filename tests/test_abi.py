@@ -1,4 +1,4 @@
-"""CPU: the C-ABI library builds/loads, exports every symbol include/vallex_hip.h declares, and the product path
+"""CPU: the C-ABI library builds/loads, exports every symbol include/vallex_hip.h and include/vallex_hip_dev.h declare, and the product path
 fails loudly (no CPU fallback, no oracle import) when there is no GPU."""
 import os
 import re
@@ -19,12 +19,16 @@ def lib():
 
 
 def test_header_symbols_exported(lib):
-    hdr = open(os.path.join(ROOT, "include", "vallex_hip.h")).read()
-    declared = set(re.findall(r"\b(vx_[a-z_]+)\s*\(", hdr))
-    from vallex_amd._capi import SYMBOLS
-    assert declared == set(SYMBOLS)
-    for s in declared:
-        assert hasattr(lib, s), s
+    from vallex_amd._capi import DEV_SYMBOLS, SYMBOLS
+    for header, syms in (("vallex_hip.h", SYMBOLS), ("vallex_hip_dev.h", DEV_SYMBOLS)):
+        hdr = open(os.path.join(ROOT, "include", header)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        declared = set(re.findall(r"\b(vx_[a-z_]+)\s*\(", hdr))
+        assert declared == set(syms), header
+        for s in declared:
+            assert hasattr(lib, s), s
+    # the drop-in boundary carries no measurement entry
+    assert not [s for s in SYMBOLS if s.startswith(("vx_bench", "vx_prof"))]
 
 
 def test_struct_layout_matches_header():

@@ -1,5 +1,5 @@
 """CPU: the development tools stay loadable -- every Python tool parses, every shell script passes `bash -n`, and the experiments
-kept as patches under tools/experiments/ still apply to the product sources (so a measured dead end can be re-measured)."""
+kept as patches under tools/experiments/ apply to the commit they name (so a measured dead end can be re-measured)."""
 import ast
 import glob
 import os
@@ -26,13 +26,24 @@ def test_shell_tools_are_valid_bash():
         assert r.returncode == 0, (f, r.stderr)
 
 
-def test_experiment_patches_still_apply():
+def test_experiment_patches_apply_to_their_base_commit(tmp_path):
+    """every patch names the commit it was measured on (`# base: <sha>` in its first line) and applies to THAT tree -- the
+    product sources move on, a measured dead end stays re-measurable"""
     if shutil.which("git") is None or not os.path.isdir(os.path.join(ROOT, ".git")):
         pytest.skip("not a git checkout (the GPU box runs from a snapshot)")
     patches = glob.glob(os.path.join(ROOT, "tools", "experiments", "*.patch"))
     assert patches
     for p in patches:
-        r = subprocess.run(["git", "apply", "--check", p], cwd=ROOT, capture_output=True, text=True)
+        first = open(p).readline()
+        assert first.startswith("# base: "), (os.path.basename(p), "first line must be `# base: <commit>`")
+        base = first.split()[2]
+        files = [ln.split(" b/", 1)[1].strip() for ln in open(p) if ln.startswith("diff --git ")]
+        d = tmp_path / os.path.basename(p)
+        d.mkdir()
+        tar = subprocess.run(["git", "archive", base] + files, cwd=ROOT, capture_output=True)
+        assert tar.returncode == 0, tar.stderr
+        subprocess.run(["tar", "-x", "-C", str(d)], input=tar.stdout, check=True)
+        r = subprocess.run(["git", "apply", "--check", p], cwd=str(d), capture_output=True, text=True)
         assert r.returncode == 0, (os.path.basename(p), r.stderr)
 
 

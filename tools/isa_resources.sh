@@ -9,8 +9,17 @@ OUT=profiles/r${R}_isa_resources.txt
 TMP=$(mktemp -d)
 : > "$OUT"
 printf "%-58s %5s %5s %7s %7s %4s\n" "kernel (source)" VGPR AGPR scratch LDS occ >> "$OUT"
+# the product's own flags and per-source extras (vall-e-x_amd/_build.py is the one place they are written down)
+flags_of() { python3 - "$1" <<'PY'
+import importlib.util, os, sys
+spec = importlib.util.spec_from_file_location("_vx_build", os.path.join("vall-e-x_amd", "_build.py"))
+m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+print(" ".join(m.FLAGS + m.EXTRA_FLAGS.get(sys.argv[1], [])))
+PY
+}
 for f in vall-e-x_amd/csrc/*.hip; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -mllvm -amdgpu-kernarg-preload-count=16 -Rpass-analysis=kernel-resource-usage \
+  # shellcheck disable=SC2046
+  /opt/rocm/bin/hipcc $(flags_of "$(basename "$f")") -Rpass-analysis=kernel-resource-usage \
       -c "$f" -o "$TMP/x.o" 2> "$TMP/log" || { cat "$TMP/log"; exit 1; }
   python3 - "$TMP/log" "$(basename "$f")" >> "$OUT" <<'PY'
 import re, sys, subprocess

@@ -9,8 +9,12 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libvallex_hip.so")
-SOURCES = ["gemm_f32.hip", "gemm_f16x2.hip", "gemm_bf16x3.hip", "gemm_bf16x3_dma.hip", "rows.hip", "attn_full.hip", "attn_full_x3.hip", "attn_full_h2.hip", "decode.hip", "vocos.hip", "encodec.hip", "engine.hip"]
-HEADERS = ["vx_common.h", os.path.join("..", "..", "include", "vallex_hip.h")]
+SOURCES = ["gemm_f32.hip", "gemm_f16x2.hip", "gemm_bf16x3.hip", "gemm_bf16x3_dma.hip", "rows.hip", "attn_full.hip", "attn_full_x3.hip", "attn_full_h2.hip", "decode.hip", "vocos.hip", "encodec.hip", "engine.hip", "weights.hip", "vocoders.hip", "bench_harness.hip"]
+HEADERS = ["vx_common.h"]                    # every translation unit
+# the engine's translation units (host code: context, drivers, C ABI) also see the internal context header and the public ABI
+ENGINE_TUS = ("engine.hip", "weights.hip", "vocoders.hip", "bench_harness.hip")
+ENGINE_HEADERS = ["engine_ctx.h", os.path.join("..", "..", "include", "vallex_hip.h"),
+                  os.path.join("..", "..", "include", "vallex_hip_dev.h")]
 # kernarg preload: the first kernel arguments arrive in SGPRs with the wave instead of through an s_load round trip at the
 # head of every launch (the compiler keeps a compatibility prologue for firmware without the feature)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result",
@@ -60,7 +64,8 @@ def build_library(force: bool = False, verbose: bool = False, dev: bool = False,
     """dev=True: a SEPARATE library with the kernels' timing probes compiled in (-DVX_DEV_PROBES), for tools/gemm_bench.py and
     tools/attn_bench.py only (tools/dev/libvallex_hip.so); the product library never contains them."""
     force = force or os.environ.get("VX_FORCE_BUILD", "") == "1"
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    hdrs_common = [os.path.join(CSRC, h) for h in HEADERS]
+    hdrs_engine = hdrs_common + [os.path.join(CSRC, h) for h in ENGINE_HEADERS]
     objs, jobs = [], []
     out_dir = os.path.join(os.path.dirname(HERE), "tools", "dev") if dev else CSRC
     extra = dict(EXTRA_FLAGS)
@@ -80,6 +85,7 @@ def build_library(force: bool = False, verbose: bool = False, dev: bool = False,
         obj = os.path.join(out_dir, s.replace(".hip", ".o"))
         objs.append(obj)
         fl = flags + extra.get(s, [])
+        hdrs = hdrs_engine if s in ENGINE_TUS else hdrs_common
         if force or _stale(obj, [src] + hdrs, fl):
             jobs.append(([_hipcc()] + fl + ["-c", src, "-o", obj], obj, [src] + hdrs, fl))
 

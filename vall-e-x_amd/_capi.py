@@ -1,4 +1,5 @@
-"""ctypes binding of include/vallex_hip.h -- the only way the Python layer reaches the GPU.
+"""ctypes binding of include/vallex_hip.h (the drop-in boundary) and include/vallex_hip_dev.h (measurement entries) -- the only
+way the Python layer reaches the GPU.
 
 There is deliberately NO CPU fallback: if libvallex_hip.so is missing or no HIP device is present the calls
 raise (VallexHipError / OSError); nothing here imports oracle/.
@@ -49,9 +50,10 @@ ABI_VERSION = 4       # VX_ABI_VERSION of include/vallex_hip.h this binding was 
 
 SYMBOLS = ["vx_abi_version", "vx_create", "vx_destroy", "vx_last_error", "vx_synchronize", "vx_load_tensor", "vx_finalize_weights",
            "vx_infer", "vx_vocos_decode", "vx_encodec_decode", "vx_encodec_encode", "vx_ar_prefill", "vx_ar_logits", "vx_ar_step",
-           "vx_nar", "vx_read_tap",
-           "vx_prof_enable", "vx_prof_get", "vx_prof_reset", "vx_bench_kernel", "vx_bench_gemm", "vx_bench_attn", "vx_last_stats", "vx_last_truncated",
-           "vx_last_fallbacks", "vx_arith_mode"]
+           "vx_nar", "vx_read_tap", "vx_last_stats", "vx_last_truncated", "vx_last_fallbacks", "vx_arith_mode"]
+# ... and include/vallex_hip_dev.h: measurement / kernel development, never called by the mirrors of the reference API
+DEV_SYMBOLS = ["vx_prof_enable", "vx_prof_get", "vx_prof_reset", "vx_bench_kernel", "vx_bench_gemm", "vx_bench_attn",
+               "vx_bench_gemm_clock"]
 
 _lib = None
 
@@ -97,11 +99,13 @@ def load_library() -> C.CDLL:
     lib.vx_bench_kernel.argtypes = [ctx, C.c_int32, C.c_int32, C.c_int32, P(C.c_double), P(C.c_double)]
     lib.vx_bench_gemm.argtypes = [ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P(C.c_double), P(C.c_double)]
     lib.vx_bench_attn.argtypes = [ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P(C.c_double), P(C.c_double)]
+    lib.vx_bench_gemm_clock.argtypes = [ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P(C.c_double), P(C.c_double),
+                                        P(C.c_double)]
     lib.vx_last_stats.argtypes = [ctx, P(C.c_int64), P(C.c_int64), P(C.c_double), P(C.c_double)]
     lib.vx_last_truncated.argtypes = [ctx, P(C.c_int32)]
     lib.vx_last_fallbacks.argtypes = [ctx, P(C.c_int32), P(C.c_int32), P(C.c_int64)]
     lib.vx_arith_mode.argtypes = [ctx, P(C.c_int32), P(C.c_int32)]
-    for name in SYMBOLS:
+    for name in SYMBOLS + DEV_SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("vx_destroy", "vx_last_error", "vx_read_tap", "vx_abi_version"):
             fn.restype = C.c_int
@@ -321,6 +325,12 @@ class Engine:
         us, md = C.c_double(), C.c_double()
         self._chk(self.lib.vx_bench_gemm(self.ctx, M, N, K, kernel, reps, C.byref(us), C.byref(md)))
         return us.value, md.value
+
+    def bench_gemm_clock(self, M: int, N: int, K: int, kernel: int = 6, reps: int = 8):
+        """(avg_us, max |diff| to the fp32 kernel, shader clock in MHz held WHILE the kernel runs) -- include/vallex_hip_dev.h"""
+        us, md, mhz = C.c_double(), C.c_double(), C.c_double()
+        self._chk(self.lib.vx_bench_gemm_clock(self.ctx, M, N, K, kernel, reps, C.byref(us), C.byref(md), C.byref(mhz)))
+        return us.value, md.value, mhz.value
 
     def bench_attn(self, batch: int, length: int, causal: bool, variant: int, reps: int = 5):
         """variant 0 fp32 kernel / 10 bf16x3 kernel (+1..3: timing probes); returns (avg_us, max |out - fp32 out| or -1)"""

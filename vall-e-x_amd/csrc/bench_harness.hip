@@ -1,0 +1,378 @@
+// Measurement and kernel-development entries (include/vallex_hip_dev.h): per-class HIP-event profiling, back-to-back kernel
+// replays on the live decode state, stand-alone GEMM / attention micro-benchmarks.  Never on the product path.
+#include "../../include/vallex_hip_dev.h"
+#include "engine_ctx.h"
+
+namespace {
+
+// Kernel-development aid (VX_BENCH_CLOCK=1 in vx_bench_gemm): one wave that sits next to the kernel under test for `ref_ticks` of
+// the constant 100 MHz counter and reports how many shader-clock ticks (s_memtime) went by -> the clock the chip actually
+// holds under that load.  Bounded by the real-time counter, so it always terminates.
+__global__ void clock_probe_kernel(unsigned long long* out, unsigned long long ref_ticks) {
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_readcyclecounter();
+  while (__builtin_amdgcn_s_memrealtime() - r0 < ref_ticks) __builtin_amdgcn_s_sleep(16);
+  if (threadIdx.x == 0) {
+    out[0] = __builtin_readcyclecounter() - c0;
+    out[1] = __builtin_amdgcn_s_memrealtime() - r0;
+  }
+}
+
+
+}  // namespace
+
+extern "C" {
+
+int vx_prof_enable(vx_ctx* c, int32_t on) {
+  if (!c) return VX_EINVAL;
+  c->prof_on = on;
+  return VX_OK;
+}
+
+int vx_prof_reset(vx_ctx* c) {
+  if (!c) return VX_EINVAL;
+  for (auto& p : c->prof) { p.used = 0; p.bytes = 0; }
+  return VX_OK;
+}
+
+int vx_prof_get(vx_ctx* c, int32_t which, double* total_ms, int64_t* launches, double* algo_bytes) {
+  if (!c || which < 0 || which > 4) return VX_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  ProfClass& p = c->prof[which];
+  double tot = 0;
+  for (size_t i = 0; i + 1 < p.used; i += 2) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]));
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = (int64_t)(p.used / 2);
+  if (algo_bytes) *algo_bytes = p.bytes;
+  return VX_OK;
+}
+
+// Back-to-back replays of ONE decode kernel on the live state of the last AR run, bracketed by a single HIP event
+// pair on the engine stream (GPU-bound: no host gaps inside the interval).  which 0: dec_attn of layer 0 with every
+// row's context set to prefill_len + gen_offset; which 1: the five weight-streaming GEMMs of a step's layer 0
+// (+ predict layer), reported per launch.
+int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, double* avg_us, double* algo_bytes) {
+  if (!c || reps <= 0 || !avg_us || !algo_bytes) return VX_EINVAL;
+  if (c->cur_batch <= 0) FAIL(VX_ESTATE, "no AR run to replay");
+  HIPCHK(hipSetDevice(c->dev));
+  const int nb = c->cur_batch;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  double bytes = 0;
+  int launches = 0;
+  if (which == 0) {
+    std::vector<int> ctx(nb), one(nb, 1);
+    for (int i = 0; i < nb; ++i) {
+      ctx[i] = std::min(c->h_L[i] + std::max(gen_offset, 1), c->Tmax - 1);
+      bytes += (double)ctx[i] * 2.0 * D_MODEL * 4.0;
+    }
+    if (c->fuse_out && c->nsplit == 1) bytes += (double)D_MODEL * D_MODEL * 4.0;     // + W_o, streamed once (fused out_proj)
+    // the replay's contexts go into the per-slot view dec_attn reads (the row order of the last prefill is kept)
+    std::vector<int> meta(4 * nb);
+    HIPCHK(hipMemcpyAsync(meta.data(), c->slot_meta, meta.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int y = 0; y < nb; ++y) { meta[4 * y + 1] = ctx[meta[4 * y]]; meta[4 * y + 2] = 1; }
+    HIPCHK(hipMemcpyAsync(c->slot_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->ctx_len, ctx.data(), nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->active, one.data(), nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    // rotate over the layers' KV arenas like the real step does: the working set (NL x ~178 MB at batch 32) is far beyond
+    // the 256 MiB Infinity Cache, so no launch is served from it
+    const size_t cache_layer = (size_t)c->mbr * N_HEAD * c->Tmax * D_HEAD;
+    auto attn_l = [&](int r) {
+      const int l = r % c->NL;
+      const bool fused = c->fuse_out && c->nsplit == 1;
+      launch_dec_attn(c->p_qkv, SK_QKV, c->ar[l].in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax,
+                      c->slot_meta, c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, fused ? c->ar[l].out_wh : nullptr, c->p_oh,
+                      c->stream);
+    };
+    for (int w = 0; w < 3; ++w) attn_l(w);
+    HIPCHK(hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; ++r) attn_l(r);
+    HIPCHK(hipEventRecord(e1, c->stream));
+    launches = reps;
+  } else if (which == 1) {
+    const LayerW& L = c->ar[0];
+    auto seq = [&]() {
+      launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, c->stream);
+      launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, c->stream);
+      launch_skinny16_relu_pack(L.l1_wp, c->xp, L.l1_b, c->xp4, D_FF, D_MODEL, c->stream);
+      launch_skinny_gemm(L.l2_wp, c->xp4, c->p_o, D_MODEL, D_FF, SK_L2, c->stream);
+    };
+    seq();
+    HIPCHK(hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; ++r) seq();
+    HIPCHK(hipEventRecord(e1, c->stream));
+    launches = reps * 4;
+    bytes = 12.0 * D_MODEL * D_MODEL * 4.0 / 4.0;     // per launch: a layer's 12 d^2 weights over its 4 GEMMs
+  } else if (which == 2) {
+    // cache-retention probe: the SAME weight-streaming GEMM (layer 0 QKV, 12.6 MB) back to back -- what a launch costs when
+    // its weights were read a moment ago (memory-side cache hits) instead of coming cold from HBM (which 1)
+    const LayerW& L = c->ar[0];
+    auto one = [&]() { launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, c->stream); };
+    one();
+    HIPCHK(hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; ++r) one();
+    HIPCHK(hipEventRecord(e1, c->stream));
+    launches = reps;
+    bytes = 3.0 * D_MODEL * D_MODEL * 4.0;
+#ifdef VX_DEV_PROBES
+  } else if (which == 3) {
+    // development timeline (tools/step_timeline.py): `reps` graph replays of a ONE-layer decode step (QKV | attention |
+    // reduce+LN | linear1 | linear2 | reduce+LN | predict | sampler) on the live state; the kernels stamp the wall clock
+    // (decode.hip) and the caller fetches the stamps of the last replay with vx_dev_stamps.
+    vx_sampling sp{};
+    sp.struct_size = sizeof(vx_sampling); sp.top_k = 10; sp.temperature = 1.0f; sp.seed = 1; sp.force_eos_at = -1; sp.best_of = 1;
+    SampleArgs sa = make_sample_args(c, &sp, 1, nullptr);
+    const int nl_keep = c->NL;
+    c->NL = 1;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    ar_step_launches(c, &sa);
+    HIPCHK(hipStreamEndCapture(c->stream, &g));
+    c->NL = nl_keep;
+    HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    for (int w = 0; w < 3; ++w) HIPCHK(hipGraphLaunch(ge, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    dev_clear_stamps();
+    HIPCHK(hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; ++r) HIPCHK(hipGraphLaunch(ge, c->stream));
+    HIPCHK(hipEventRecord(e1, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipGraphExecDestroy(ge);
+    launches = reps;
+    bytes = 0;
+#endif
+  } else {
+    FAIL(VX_EINVAL, "which must be 0, 1 or 2");
+  }
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_us = (double)ms * 1e3 / launches;
+  *algo_bytes = bytes;
+  HIPCHK(hipGetLastError());
+  return VX_OK;
+}
+
+#ifdef VX_DEV_PROBES
+extern "C" int vx_dev_stamps(unsigned long long* out) { dev_read_stamps(out); return VX_OK; }
+extern "C" int vx_dev_gemm_stamps(unsigned long long* out) { dev_read_gemm_stamps(out); return VX_OK; }
+#endif
+
+// Stand-alone GEMM micro-benchmark on scratch buffers (kernel development aid; never on the product path):
+// kernel 0 = gemm_f32, 1 = gemm_bf16x3, 2 = gemm_bf16x3_dma, 6 = gemm_f16x2 (the default of the model path);
+// 11-13 / 21-24 = timing probes of the bf16x3 kernels (VX_DEV_PROBES builds only).  Reports the average launch time and the max abs
+// difference of the first and last 256 output rows against the fp32-MFMA kernel.
+static int bench_gemm_impl(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, int32_t reps, double* avg_us,
+                           double* max_abs_diff, double* clock_mhz) {
+  if (!c || M <= 0 || N <= 0 || K <= 0 || K % 32 || N % 4 || reps <= 0 || !avg_us || !max_abs_diff) return VX_EINVAL;
+#ifndef VX_DEV_PROBES
+  if (kernel != 0 && kernel != 1 && kernel != 2 && (kernel < 6 || kernel > 10))
+    FAIL(VX_EINVAL, "kernel must be 0, 1, 2 or 6 .. 10 (probes need a VX_DEV_PROBES build)");
+#endif
+  HIPCHK(hipSetDevice(c->dev));
+  float *A = nullptr, *Wt = nullptr, *C0 = nullptr, *C1 = nullptr;
+  unsigned short *A3 = nullptr, *W3 = nullptr;
+  auto cleanup = [&]() { for (void* p : {(void*)A, (void*)Wt, (void*)C0, (void*)C1, (void*)A3, (void*)W3}) if (p) (void)hipFree(p); };
+  hipError_t he;
+#define TRY(x) if ((he = (x)) != hipSuccess) { cleanup(); c->err = std::string(#x) + ": " + hipGetErrorString(he); return VX_EHIP; }
+  TRY(hipMalloc((void**)&A, (size_t)M * K * 4));
+  TRY(hipMalloc((void**)&Wt, (size_t)N * K * 4));
+  TRY(hipMalloc((void**)&C0, (size_t)M * N * 4));
+  TRY(hipMalloc((void**)&C1, (size_t)M * N * 4));
+  TRY(hipMalloc((void**)&A3, (size_t)3 * h2_plane(M, K, H2_TILE_A) * 2));
+  TRY(hipMalloc((void**)&W3, (size_t)3 * h2_plane(N, K, H2_TILE_W) * 2));
+  TRY(hipMemset(A3, 0, (size_t)3 * h2_plane(M, K, H2_TILE_A) * 2));
+  TRY(hipMemset(W3, 0, (size_t)3 * h2_plane(N, K, H2_TILE_W) * 2));
+  {
+    std::vector<float> h((size_t)std::max(M, N) * K);
+    unsigned long long st = 0x9E3779B97F4A7C15ull;
+    auto fill = [&](size_t n) { for (size_t i = 0; i < n; ++i) { st = st * 6364136223846793005ull + 1442695040888963407ull; h[i] = (float)((st >> 40) & 0xFFFFFF) / 8388608.0f - 1.0f; } };
+    fill((size_t)M * K);
+    TRY(hipMemcpy(A, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice));
+    fill((size_t)N * K);
+    TRY(hipMemcpy(Wt, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice));
+  }
+  GemmArgs g0{};
+  g0.A = A; g0.lda = K; g0.W = Wt; g0.ldw = K; g0.C = C0; g0.ldc = N; g0.M = M; g0.N = N; g0.K = K; g0.act = ACT_NONE;
+  launch_gemm_f32(g0, c->stream);
+  if ((kernel >= 6 && kernel <= 10) || kernel >= 61) {   // fp16 head / tail planes
+    launch_split2h(A, K, M, K, nullptr, A3, h2_plane(M, K, H2_TILE_A), H2_TILE_A, nullptr, H2_ACT_SCALE, c->stream);
+    launch_split2h(Wt, K, N, K, nullptr, W3, h2_plane(N, K, H2_TILE_W), H2_TILE_W, nullptr, 16384.0f, c->stream);   // |w| < 1
+  } else {
+    launch_split3(A, K, M, K, nullptr, A3, (long)M * K, c->stream);
+    launch_split3(Wt, K, N, K, nullptr, W3, (long)N * K, c->stream);
+  }
+  GemmX3Args gx{};
+  const bool h2 = (kernel >= 6 && kernel <= 10) || kernel >= 61;
+  gx.A = A3; gx.a_plane = h2 ? h2_plane(M, K, H2_TILE_A) : (long)M * K; gx.W = W3; gx.w_plane = h2 ? h2_plane(N, K, H2_TILE_W) : (long)N * K; gx.C = C1; gx.ldc = N; gx.M = M; gx.N = N; gx.K = K;
+  gx.act = ACT_NONE;
+  gx.descale = ldexpf(1.0f, -(H2_ACT_SHIFT + 14));
+  GemmArgs g1 = g0;
+  g1.C = C1;
+  auto run = [&]() {
+    if (kernel == 0) launch_gemm_f32(g1, c->stream);
+    else if (kernel == 1) launch_gemm_bf16x3(gx, c->stream);
+    else if (kernel == 2) launch_gemm_bf16x3_dma(gx, c->stream);
+    else if (kernel == 6) launch_gemm_f16x2(gx, c->stream);              // the product's choice of tile
+    else if (kernel == 7) launch_gemm_f16x2(gx, c->stream, 128);
+    else if (kernel == 8) launch_gemm_f16x2(gx, c->stream, 256);
+    else if (kernel == 9) launch_gemm_f16x2(gx, c->stream, -128);         // 128 x 128 tiles (the short-row-set kernel) forced
+    else if (kernel == 10) launch_gemm_f16x2(gx, c->stream, -129);        // ... with two LDS stages forced (A/B of the four-stage ring)
+#ifdef VX_DEV_PROBES
+    else if (kernel >= 61) launch_gemm_f16x2_probe(gx, kernel - 60, c->stream);         // 61-64: probes of the f16x2 kernel
+    else if (kernel >= 21) launch_gemm_bf16x3_dma_probe(gx, kernel - 20, c->stream);   // 21-24: probes of the DMA kernel
+    else launch_gemm_bf16x3_probe(gx, kernel - 10, c->stream);      // 11 / 12 / 13: timing probes
+#endif
+  };
+  run();
+  // VX_BENCH_CLOCK=1: sample the shader clock on a second stream while the timed launches run (power / clock ceiling check)
+  const char* want_clock = getenv("VX_BENCH_CLOCK");
+  hipStream_t s2 = nullptr;
+  unsigned long long* d_clk = nullptr;
+  if (clock_mhz) *clock_mhz = 0.0;
+  if (clock_mhz || (want_clock && want_clock[0] == '1')) {
+    TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    TRY(hipMalloc((void**)&d_clk, 16));
+    TRY(hipStreamSynchronize(c->stream));
+  }
+  hipEvent_t e0, e1;
+  TRY(hipEventCreate(&e0));
+  TRY(hipEventCreate(&e1));
+  TRY(hipEventRecord(e0, c->stream));
+  run();                                                           // the probe starts once the device is busy
+  if (s2) hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, s2, d_clk, 100ull * 2000ull);   // 2 ms at 100 MHz
+  for (int r = 1; r < reps; ++r) run();
+  TRY(hipEventRecord(e1, c->stream));
+  TRY(hipEventSynchronize(e1));
+  float ms = 0;
+  TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_us = (double)ms * 1e3 / reps;
+  if (s2) {
+    unsigned long long hclk[2] = {0, 0};
+    TRY(hipStreamSynchronize(s2));
+    TRY(hipMemcpy(hclk, d_clk, 16, hipMemcpyDeviceToHost));
+    const double mhz = hclk[1] ? (double)hclk[0] / ((double)hclk[1] / 100.0) : 0.0;
+    if (clock_mhz) *clock_mhz = mhz;
+    else
+      fprintf(stderr, "[vx_bench_gemm] kernel %d M=%d N=%d K=%d: shader clock while running = %.0f MHz (%llu ticks in %.3f ms)\n", kernel,
+              M, N, K, mhz, hclk[0], (double)hclk[1] / 1e5);
+    (void)hipFree(d_clk);
+    (void)hipStreamDestroy(s2);
+  }
+  const int rows = std::min(M, 256);
+  std::vector<float> h0((size_t)rows * N), h1((size_t)rows * N);
+  TRY(hipMemcpy(h0.data(), C0, h0.size() * 4, hipMemcpyDeviceToHost));
+  TRY(hipMemcpy(h1.data(), C1, h1.size() * 4, hipMemcpyDeviceToHost));
+  // also the LAST rows (tile tails)
+  double md = 0;
+  for (size_t i = 0; i < h0.size(); ++i) md = std::max(md, (double)fabsf(h0[i] - h1[i]));
+  TRY(hipMemcpy(h0.data(), C0 + (size_t)(M - rows) * N, h0.size() * 4, hipMemcpyDeviceToHost));
+  TRY(hipMemcpy(h1.data(), C1 + (size_t)(M - rows) * N, h1.size() * 4, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < h0.size(); ++i) md = std::max(md, (double)fabsf(h0[i] - h1[i]));
+  *max_abs_diff = md;
+#undef TRY
+  cleanup();
+  HIPCHK(hipGetLastError());
+  return VX_OK;
+}
+
+int vx_bench_gemm(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, int32_t reps, double* avg_us,
+                  double* max_abs_diff) {
+  return bench_gemm_impl(c, M, N, K, kernel, reps, avg_us, max_abs_diff, nullptr);
+}
+
+int vx_bench_gemm_clock(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, int32_t reps, double* avg_us,
+                        double* max_abs_diff, double* clock_mhz) {
+  if (!clock_mhz) return VX_EINVAL;
+  return bench_gemm_impl(c, M, N, K, kernel, reps, avg_us, max_abs_diff, clock_mhz);
+}
+
+// kernel-development aid: time attn_full (variant 0) or one of its probes (1 no staging, 2 no MFMA, 3 no softmax) on
+// random q|k|v for `batch` sequences of length `len`, unmasked (NAR) or prefix-LM with prefix = len/3 (causal != 0).
+int vx_bench_attn(vx_ctx* c, int32_t batch, int32_t len, int32_t causal, int32_t variant, int32_t reps, double* avg_us,
+                  double* max_diff) {
+  // variant: 0 fp32 kernel, 1-3 its probes; 10 bf16x3 kernel, 11-13 its probes.  max_diff (optional) = max |out - out of
+  // the fp32 kernel| for the product variants (0 / 10), -1 for probes.
+  if (!c || batch <= 0 || len <= 0 || reps <= 0 || !avg_us) return VX_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  const long M = (long)batch * len;
+  float *qkv = nullptr, *out = nullptr, *ref = nullptr;
+  int* meta = nullptr;
+  auto cleanup = [&]() { for (void* p : {(void*)qkv, (void*)out, (void*)ref, (void*)meta}) if (p) (void)hipFree(p); };
+  hipError_t he;
+#define TRY(x) if ((he = (x)) != hipSuccess) { cleanup(); c->err = std::string(#x) + ": " + hipGetErrorString(he); return VX_EHIP; }
+  TRY(hipMalloc((void**)&qkv, (size_t)M * 3 * D_MODEL * 4));
+  TRY(hipMalloc((void**)&out, (size_t)M * D_MODEL * 4));
+  TRY(hipMalloc((void**)&ref, (size_t)M * D_MODEL * 4));
+  TRY(hipMalloc((void**)&meta, (size_t)3 * batch * 4));
+  {
+    std::vector<float> h((size_t)M * 3 * D_MODEL);
+    unsigned long long st = 0x9E3779B97F4A7C15ull;
+    for (auto& v : h) { st = st * 6364136223846793005ull + 1442695040888963407ull; v = (float)((st >> 40) & 0xFFFFFF) / 8388608.0f - 1.0f; }
+    // Q columns x4: scores of a few units instead of ~0.3, so the softmax is not nearly uniform
+    for (long r = 0; r < M; ++r) for (int k = 0; k < D_MODEL; ++k) h[(size_t)r * 3 * D_MODEL + k] *= 4.0f;
+    TRY(hipMemcpy(qkv, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    std::vector<int> m(3 * batch);
+    for (int i = 0; i < batch; ++i) { m[i] = i * len; m[batch + i] = len; m[2 * batch + i] = len / 3; }
+    TRY(hipMemcpy(meta, m.data(), m.size() * 4, hipMemcpyHostToDevice));
+  }
+  const int* pre = causal ? meta + 2 * batch : nullptr;
+  auto run = [&]() {
+    if (variant == 0) launch_attn_full(qkv, out, meta, meta + batch, pre, batch, len, c->stream);
+#ifdef VX_DEV_PROBES
+    else if (variant < 10) launch_attn_full_probe(qkv, out, meta, meta + batch, pre, batch, len, variant, c->stream);
+#else
+    else if (variant < 10) return;
+#endif
+    else if (variant == 20) launch_attn_full_h2(qkv, out, meta, meta + batch, pre, batch, len, c->stream, nullptr, 0, nullptr);
+    else launch_attn_full_x3(qkv, out, meta, meta + batch, pre, batch, len, variant - 10, c->stream);
+  };
+  run();
+  hipEvent_t e0, e1;
+  TRY(hipEventCreate(&e0));
+  TRY(hipEventCreate(&e1));
+  TRY(hipEventRecord(e0, c->stream));
+  for (int r = 0; r < reps; ++r) run();
+  TRY(hipEventRecord(e1, c->stream));
+  TRY(hipEventSynchronize(e1));
+  float ms = 0;
+  TRY(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_us = (double)ms * 1e3 / reps;
+  if (max_diff) {
+    *max_diff = -1.0;
+    if (variant == 0 || variant == 10 || variant == 20) {
+      launch_attn_full(qkv, ref, meta, meta + batch, pre, batch, len, c->stream);
+      TRY(hipStreamSynchronize(c->stream));
+      std::vector<float> ho((size_t)M * D_MODEL), hr((size_t)M * D_MODEL);
+      TRY(hipMemcpy(ho.data(), out, ho.size() * 4, hipMemcpyDeviceToHost));
+      TRY(hipMemcpy(hr.data(), ref, hr.size() * 4, hipMemcpyDeviceToHost));
+      double md = 0;
+      for (size_t i = 0; i < ho.size(); ++i) {
+        const double d = std::fabs((double)ho[i] - (double)hr[i]);
+        md = (d > md || d != d) ? (d != d ? 1e30 : d) : md;
+      }
+      *max_diff = md;
+    }
+  }
+#undef TRY
+  cleanup();
+  HIPCHK(hipGetLastError());
+  return VX_OK;
+}
+
+}  // extern "C"
