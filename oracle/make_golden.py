@@ -159,6 +159,15 @@ RANGE_CASES = {
     "nl2_range_v": ("nl2_sharp_greedy", "v"),
     "nl2_range_k": ("nl2_sharp_topk10", "k"),
 }
+# Precision, not range (round 4): one weight per projection tensor at 1000 x the init bound (synth.outlier_state_dict) -- the per-tensor
+# power-of-two scale of the f16x2 weight planes is then set by the outlier and every ordinary weight sits 10 bits lower in its
+# fp16 head + tail pair.  A different function than the base weights, so it has its own live-reference golden (with margins).
+OUTLIER_CASES = {
+    "nl2_outlier1000": dict(num_layers=2, seed=3, eos_gain=1.0, outlier=1000.0, preset="paimon", n_text=16, lang="en", top_k=10,
+                            force_eos_at=48, useed=1234, full=True),
+    "nl2_outlier1000_greedy": dict(num_layers=2, seed=5, eos_gain=1.0, outlier=1000.0, preset="librispeech_1", n_text=14, lang="en",
+                                   top_k=1, force_eos_at=48, useed=None, full=True),
+}
 FULL_LOGIT_EVERY = 50          # AR logits are stored for steps 0, 50, ..., 550 (+ the forced-EOS step is not stored)
 
 # Shapes and languages of ALL 41 reference presets (presets/*.npz: frames, prompt text ids, lang_code zh 0 / ja 1 / en 2) -- metadata
@@ -228,13 +237,15 @@ def case_state_dict(c):
     sd = synth.vallex_state_dict(c["num_layers"], c["seed"], c["eos_gain"], c.get("attn_gain", 1.0))
     if c.get("range_kind"):
         sd = synth.out_of_range_state_dict(sd, c["num_layers"], c["range_kind"])
+    if c.get("outlier"):
+        sd = synth.outlier_state_dict(sd, c["num_layers"], c["outlier"])
     return sd
 
 
 def all_cases():
     """every named single-call case (name -> dict); RANGE_CASES are their base case + `range_kind`"""
     out = {}
-    for grp in (CASES, SHARP_CASES, EDGE_CASES, MAX_CASES, FULL_CASES, TRAINED_CASES, LONG_CASES, UI_CASES):
+    for grp in (CASES, SHARP_CASES, EDGE_CASES, MAX_CASES, FULL_CASES, TRAINED_CASES, LONG_CASES, UI_CASES, OUTLIER_CASES):
         out.update(grp)
     for name, (base, kind) in RANGE_CASES.items():
         out[name] = dict(out[base], range_kind=kind)
@@ -405,7 +416,8 @@ def main(only=None):
               flush=True)
     for name, c in (list(CASES.items()) + list(SHARP_CASES.items()) + list(EDGE_CASES.items()) + list(MAX_CASES.items())
                     + list(FULL_CASES.items())
-                    + list(TRAINED_CASES.items()) + list(LONG_CASES.items()) + list(UI_CASES.items())):
+                    + list(TRAINED_CASES.items()) + list(LONG_CASES.items()) + list(UI_CASES.items())
+                    + list(OUTLIER_CASES.items())):
         if only and name not in only:
             continue
         if c.get("full") and not only and os.path.exists(os.path.join(GOLD, name + ".npz")):

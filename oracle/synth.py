@@ -222,6 +222,26 @@ def out_of_range_state_dict(sd: "OrderedDict[str, np.ndarray]", num_layers: int,
     return out
 
 
+def outlier_state_dict(sd: "OrderedDict[str, np.ndarray]", num_layers: int, factor: float = 1000.0) -> "OrderedDict[str, np.ndarray]":
+    """A DIFFERENT function than `sd` (its golden comes from the live reference run on these weights): ONE element of every
+    transformer projection weight -- in_proj, out_proj, linear1, linear2 of both stacks -- is set to `factor` x the init bound
+    of its tensor (31.25 for K = 1024, 15.6 for K = 4096 at factor 1000).  The f16x2 kernels scale each weight tensor by a
+    power of two chosen from its own max |w|: with the maximum set by one outlier all the ordinary
+    weights sit 10 bits lower in the fp16 head + tail pair -- the case where the format loses PRECISION (tails drifting towards
+    fp16 subnormals) rather than range.  The range guard is not expected to fire."""
+    out = OrderedDict()
+    copied = {}
+    for k, v in sd.items():                                   # keep the tying (same array object under two keys)
+        copied.setdefault(id(v), v.copy())
+        out[k] = copied[id(v)]
+    for i, p in enumerate(_layer_prefixes(num_layers)):
+        for j, name in enumerate(("self_attn.in_proj_weight", "self_attn.out_proj.weight", "linear1.weight", "linear2.weight")):
+            w = out[p + name]
+            n, k = (7 + 13 * i + 5 * j) % w.shape[0], (11 + 17 * i + 3 * j) % w.shape[1]
+            w[n, k] = np.float32(factor / np.sqrt(w.shape[1])) * (np.float32(-1.0) if (i + j) & 1 else np.float32(1.0))
+    return out
+
+
 def vocos_state_dict(seed: int = 2) -> "OrderedDict[str, np.ndarray]":
     """Synthetic weights in the key layout of `charactr/vocos-encodec-24khz`
     (recalled from the pip `vocos` package, SURVEY.md §A.5 -- parity unpinned)."""

@@ -44,7 +44,7 @@ def case_model(c, arith="default", **kw):
     arithmetic of the full-sequence path (vx_config.arith).  The state-dict is cached per weight recipe: the 12-layer
     trained-like one takes ~20 s of CPU to build and is shared by the three arithmetic modes."""
     from oracle.make_golden import case_state_dict
-    wkey = (c["num_layers"], c["seed"], c.get("eos_gain", 1.0), c.get("attn_gain", 1.0), bool(c.get("trained")), c.get("range_kind"))
+    wkey = (c["num_layers"], c["seed"], c.get("eos_gain", 1.0), c.get("attn_gain", 1.0), bool(c.get("trained")), c.get("range_kind"), c.get("outlier"))
     opts = dict(vocos=False, debug_taps=False, max_new=320, max_prompt=400, max_text=256, max_batch=32, use_graph=True)
     opts.update(kw)
     key = ("case", wkey, arith) + tuple(sorted(opts.items()))

@@ -107,3 +107,43 @@ def test_fallback_with_best_of_beams_and_continual():
     out = m.continual(text, np.array([text.shape[-1]]), y)
     assert m.engine.last_fallbacks() == dict(prefill=0, nar=1, lifetime=1)
     np.testing.assert_array_equal(np.asarray(out), golden("nl2_continual")["codes"])
+
+
+def test_outlier_weights_lose_no_ids_and_need_no_fallback():
+    """PRECISION rather than range: one weight per projection tensor at 1000 x the init bound.  Each weight tensor's f16x2 planes
+    are scaled from its own max |w|, so the outlier pushes every ordinary weight 10 bits down in its fp16 head + tail pair (tails
+    towards fp16 subnormals).  Ids must still be the live reference's, logits within the goldens' margins, and the range guard
+    must stay silent (nothing is out of RANGE)."""
+    from oracle.make_golden import OUTLIER_CASES
+    from tests._util import nar_logit_error, teacher_forced_logit_error
+    for name, c in sorted(OUTLIER_CASES.items()):
+        g = golden(name)
+        row, us = inputs_row(c)
+        for arith in ("f16x2", "f32"):
+            m = case_model(c, arith=arith, debug_taps=True)
+            out = _run(m, c, [row], None if us is None else us[:, None])[0]
+            assert m.engine.last_fallbacks()["lifetime"] == 0, (name, arith)
+            assert_codes(f"{name} [{arith}]", out, g)
+            worst, flips = teacher_forced_logit_error(m, row, g, 50)
+            assert worst <= 1e-4, (name, arith, worst)                   # reference's own smallest AR margin here: 1.7e-4
+            if c["top_k"] == 1:
+                assert flips == 0, (name, arith, flips)
+            codes, errs = nar_logit_error(m, row, g)
+            assert max(errs) <= 2e-3, (name, arith, errs)                # smallest NAR margin: 2.8e-2
+            assert_codes(f"{name} NAR [{arith}]", codes, g)
+
+
+def test_a_model_that_keeps_leaving_the_range_goes_straight_to_fp32():
+    """sticky fallback: after two raises of a phase kind the context runs that kind on the fp32 kernels directly -- every call
+    still returns the reference's ids and still reports the phases it ran in fp32"""
+    base, kind = RANGE_CASES["nl2_range_ffn"]
+    c = ALL["nl2_range_ffn"]
+    row, us = inputs_row(c)
+    m = case_model(c)
+    life = m.engine.last_fallbacks()["lifetime"]
+    for call in range(4):
+        out = _run(m, c, [row], None if us is None else us[:, None])[0]
+        fb = m.engine.last_fallbacks()
+        assert (fb["prefill"], fb["nar"]) == (1, 1), (call, fb)
+        assert fb["lifetime"] == life + 2 * (call + 1), (call, fb)
+        assert_codes(f"nl2_range_ffn call {call}", out, golden(base))

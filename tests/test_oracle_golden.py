@@ -224,6 +224,19 @@ def test_out_of_range_rescaling_is_the_same_function():
     assert float((x @ w.T).abs().max()) > 2047.0
 
 
+def test_oracle_matches_reference_with_outlier_weights():
+    """synth.outlier_state_dict: one weight per projection tensor at 1000 x the init bound (the per-tensor scale of the f16x2
+    weight planes is then set by the outlier; tests/test_gpu_range_fallback.py runs the engine on these).  Golden = live reference."""
+    from oracle.make_golden import OUTLIER_CASES, case_state_dict
+    for name, c in sorted(OUTLIER_CASES.items()):
+        sd = case_state_dict(c)
+        w = sd["nar_decoder.layers.1.linear1.weight"]
+        assert np.abs(w).max() > 900.0 * np.median(np.abs(w)), name                 # one element dominates the tensor
+        g = np.load(os.path.join(GOLD, name + ".npz"))
+        np.testing.assert_array_equal(_run_case(c), g["codes"], err_msg=name)
+        assert g["ar_margin"].min() > 1e-4 and g["nar_margin"].min() > 1e-3       # the reference decides these steps robustly
+
+
 SLOW = os.environ.get("VX_SLOW") == "1"
 
 

@@ -231,7 +231,22 @@ class Engine:
             warnings.warn(f"{cut.value} row(s) were cut at the engine's max_new = {self.max_new} frames before the reference's stop "
                           "rule (EOS or 16 x text length, models/vallex.py:575-578): create the engine with a larger max_new",
                           RuntimeWarning, stacklevel=2)
+        self._warn_fallbacks()
         return [out[i, : lens[i]].copy() for i in range(batch.n)]
+
+    def _warn_fallbacks(self):
+        """one warning per engine when the f16x2 range guard re-ran a phase in fp32 (vx_last_fallbacks): results are the
+        reference's either way, but a model that does this on every call runs ~3x slower than with arith='f32' chosen up front"""
+        if getattr(self, "_fb_warned", False):
+            return
+        fb = self.last_fallbacks()
+        if fb["lifetime"]:
+            import warnings
+            self._fb_warned = True
+            warnings.warn(f"activations of this model left the fp16 range of the f16x2 kernels: {fb['prefill']} prefill / {fb['nar']} NAR "
+                          "phase(s) of this call were re-run on the exact-fp32 kernels (results are exact; after two such calls the "
+                          "engine goes to fp32 directly).  If this model does it regularly, create the engine with arith='f32'.",
+                          RuntimeWarning, stacklevel=3)
 
     def vocos_decode(self, codes: Sequence[np.ndarray], bandwidth_id: int = 2):
         n = len(codes)
@@ -295,6 +310,7 @@ class Engine:
         out = np.zeros((batch.n, stride, 8), np.int64)
         self._chk(self.lib.vx_nar(self.ctx, C.byref(batch.c), _ptr(c0, C.c_int32), stride, _ptr(lens, C.c_int32),
                                   _ptr(out, C.c_int64), stride))
+        self._warn_fallbacks()
         return [out[i, : lens[i]].copy() for i in range(batch.n)]
 
     def read_tap(self, name: str, n: int) -> np.ndarray:

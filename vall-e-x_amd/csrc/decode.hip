@@ -513,7 +513,14 @@ __global__ __launch_bounds__(256) void skinny_gemm_sb_kernel(const float* __rest
   *reinterpret_cast<f32x4*>(dst + wid * 8) = t;
 }
 
-void launch_skinny_gemm_sb_ln(const float* Wp, float* partial_out, int Npad, int splitk, const float* partial_in, int sk_in,
+// The small-batch launchers compile the producer's split count into the kernel; a configuration that is not instantiated is
+// reported to the caller (false, nothing launched) -- the engine asks sb_chain_supported() first and otherwise runs the general
+// chain, and a launcher that still refuses turns into VX_EINVAL from the ABI call, never into a dead host process.
+bool sb_chain_supported(int sk_l2, int sk_out, int nsplit, int batch) {
+  return (sk_l2 == 8 || sk_l2 == 4) && sk_out == 4 && (nsplit == 16 || nsplit == 8) && batch <= SB_MAX;
+}
+
+bool launch_skinny_gemm_sb_ln(const float* Wp, float* partial_out, int Npad, int splitk, const float* partial_in, int sk_in,
                               const float* bias, const float* resid, float* h_out, const float* g, const float* b, int batch,
                               hipStream_t s) {
   if (sk_in == 8)
@@ -522,10 +529,11 @@ void launch_skinny_gemm_sb_ln(const float* Wp, float* partial_out, int Npad, int
   else if (sk_in == 4)
     hipLaunchKernelGGL((skinny_gemm_sb_kernel<0, 4>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, partial_in,
                        D_MODEL, bias, resid, h_out, g, b, nullptr, nullptr, 0, batch);
-  else { fprintf(stderr, "launch_skinny_gemm_sb_ln: split-K factor %d of the producer is not compiled in\n", sk_in); abort(); }
+  else return false;                       // split-K factor of the producer not compiled in
+  return true;
 }
 
-void launch_skinny_gemm_sb_combine(const float* Wp, float* partial_out, int Npad, int splitk, const float* part_o, const float* part_ml,
+bool launch_skinny_gemm_sb_combine(const float* Wp, float* partial_out, int Npad, int splitk, const float* part_o, const float* part_ml,
                                    int nsplit, int batch, hipStream_t s) {
   // (tried for 5 .. 8 rows as well -- BASELINE config 5 decodes 8 -- with 4 splits: 134.7 vs 138.5 audio-s/s, the 8-row prologue
   // costs more than the combine launch it removes; DESIGN.md dead-end table)
@@ -535,7 +543,8 @@ void launch_skinny_gemm_sb_combine(const float* Wp, float* partial_out, int Npad
   else if (nsplit == 8 && batch <= SB_MAX)
     hipLaunchKernelGGL((skinny_gemm_sb_kernel<1, 8>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, nullptr, 0,
                        nullptr, nullptr, nullptr, nullptr, nullptr, part_o, part_ml, nsplit, batch);
-  else { fprintf(stderr, "launch_skinny_gemm_sb_combine: %d context splits x %d rows are not compiled in\n", nsplit, batch); abort(); }
+  else return false;                       // this many context splits x rows are not compiled in
+  return true;
 }
 
 // skinny16_relu_pack_kernel (linear1) with the reduce + residual + LayerNorm of its input rows as prologue; rows 16..31 of the
@@ -597,12 +606,13 @@ __global__ __launch_bounds__(S16_WAVES * 64) void skinny16_sb_kernel(const float
   }
 }
 
-void launch_skinny16_sb_ln(const float* W16, const float* bias, float* xp_out, int N, const float* partial_in, int sk_in,
+bool launch_skinny16_sb_ln(const float* W16, const float* bias, float* xp_out, int N, const float* partial_in, int sk_in,
                            const float* pbias, const float* resid, float* h_out, const float* g, const float* b, int batch,
                            hipStream_t s) {
-  if (sk_in != 4) { fprintf(stderr, "launch_skinny16_sb_ln: split-K factor %d of the producer is not compiled in\n", sk_in); abort(); }
+  if (sk_in != 4) return false;            // split-K factor of the producer (out_proj) not compiled in
   hipLaunchKernelGGL((skinny16_sb_kernel<4>), dim3(N / 16), dim3(S16_WAVES * 64), 0, s, W16, bias, xp_out, partial_in, pbias, resid, h_out,
                      g, b, batch);
+  return true;
 }
 
 // Start of a step: embed the newest token of each row at its audio position (the reference re-embeds all of y and
@@ -900,16 +910,17 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
   VX_STAMP(6, 4);
 }
 
-void launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias, float* kc, float* vc, int Tmax,
+bool launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias, float* kc, float* vc, int Tmax,
                      const int* slot_meta, float* xp_out, float* part_o, float* part_ml, int nsplit, int batch,
                      const float* wo_heads, float* out_heads, hipStream_t s) {
-  if (splitk != 4) { fprintf(stderr, "launch_dec_attn: the QKV split-K factor is compiled in (4), got %d\n", splitk); abort(); }
+  if (splitk != 4) return false;           // the QKV split-K factor is compiled in
   if (wo_heads && nsplit == 1)
     hipLaunchKernelGGL((dec_attn_kernel<true, 4>), dim3(N_HEAD, (batch + 1) / 2, 1), dim3(ATT_WAVES * 64 * 2), 0, s, qkv_partial,
                        qkv_bias, kc, vc, Tmax, slot_meta, xp_out, part_o, part_ml, 1, wo_heads, out_heads, batch);
   else
     hipLaunchKernelGGL((dec_attn_kernel<false, 4>), dim3(N_HEAD, batch, nsplit), dim3(ATT_WAVES * 64), 0, s, qkv_partial,
                        qkv_bias, kc, vc, Tmax, slot_meta, xp_out, part_o, part_ml, nsplit, nullptr, nullptr, batch);
+  return true;
 }
 
 // W_o [1024][1024] -> head-major image for the fused out_proj: out[((h*16 + d/4)*1024 + n)*4 + d%4] = W_o[n][64h + d]
@@ -1188,11 +1199,12 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
   VX_STAMP(7, 4);
 }
 
-void launch_dec_sample(const SampleArgs& a, hipStream_t s) {
+bool launch_dec_sample(const SampleArgs& a, hipStream_t s) {
   if (a.splitk == 4) hipLaunchKernelGGL(dec_sample_kernel<4>, dim3(a.batch), dim3(64), 0, s, a);
   else if (a.splitk == 2) hipLaunchKernelGGL(dec_sample_kernel<2>, dim3(a.batch), dim3(64), 0, s, a);
   else if (a.splitk == 1) hipLaunchKernelGGL(dec_sample_kernel<1>, dim3(a.batch), dim3(64), 0, s, a);
-  else { fprintf(stderr, "launch_dec_sample: split-K factor %d is not compiled in\n", a.splitk); abort(); }
+  else return false;                       // split-K factor of the predict layer not compiled in
+  return true;
 }
 
 // best_of beams (models/vallex.py:525-527 repeats the prompt N times and prefills N times): the prefill ran ONCE, on row 0;

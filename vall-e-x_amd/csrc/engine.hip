@@ -244,7 +244,12 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
   c->cur_batch = nrows;
   // enough (row, head, split) 8-wave workgroups to put >= 2 on every CU; one split (no combine launch) from 32 rows up
   c->nsplit = std::max(1, std::min(16, 512 / (nrows * N_HEAD)));
-  if (c->sb_fuse && nrows <= SB_ROWS) c->nsplit = nrows <= 2 ? 16 : 8;      // the small-batch out_proj prologue compiles the split count in
+  // the small-batch chain compiles the split counts in (decode.hip): taken only for a combination that is instantiated
+  c->sb_chain = false;
+  if (c->sb_fuse && nrows <= SB_ROWS) {
+    const int ns = nrows <= 2 ? 16 : 8;
+    if (sb_chain_supported(SK_L2, SK_OUT, ns, nrows)) { c->nsplit = ns; c->sb_chain = true; }
+  }
 
   launch_embed_rows(c->fx, mb.dev(o_dt), W(c, "ar_text_embedding.word_embeddings.weight"), mb.dev(o_it),
                     W(c, "ar_language_embedding.word_embeddings.weight"), mb.dev(o_lt), W(c, "ar_text_position.alpha"),
@@ -319,7 +324,7 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
   if (!sa)
     launch_dec_embed_ln_pack(c->cur_tok, c->cur_pos, W(c, "ar_audio_embedding.word_embeddings.weight"),
                              W(c, "ar_audio_position.alpha"), c->pe, c->dh, c->ar[0].n1_w, c->ar[0].n1_b, c->xp, nb, st);
-  if (c->sb_fuse && nb <= SB_ROWS && c->nsplit > 1) {
+  if (c->sb_chain) {
     // small batch (BASELINE config 2: one utterance): 5 launches per layer -- QKV | dec_attn partials | out_proj | linear1 | linear2 --
     // every reduce + residual + LayerNorm and the context-split combine run in the prologue of the GEMM that consumes them
     // (decode.hip: skinny_gemm_sb_kernel, skinny16_sb_kernel).  The residual stream alternates between dh and dh2.
@@ -330,29 +335,29 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
         ProfScope ps(c, 1);
         if (l == 0) launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, st);      // xp = norm1(h) from the sampler
         else {
-          launch_skinny_gemm_sb_ln(L.in_wp, c->p_qkv, 3 * D_MODEL, SK_QKV, c->p_o, SK_L2, c->ar[l - 1].l2_b, hr, hw, L.n1_w, L.n1_b, nb, st);
+          LAUNCH(launch_skinny_gemm_sb_ln(L.in_wp, c->p_qkv, 3 * D_MODEL, SK_QKV, c->p_o, SK_L2, c->ar[l - 1].l2_b, hr, hw, L.n1_w, L.n1_b, nb, st));
           std::swap(hr, hw);
         }
       }
       {
         ProfScope ps(c, 0);
-        launch_dec_attn(c->p_qkv, SK_QKV, L.in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax, c->slot_meta,
-                        c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, nullptr, c->p_oh, st);
+        LAUNCH(launch_dec_attn(c->p_qkv, SK_QKV, L.in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax, c->slot_meta,
+                        c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, nullptr, c->p_oh, st));
       }
-      { ProfScope ps(c, 1); launch_skinny_gemm_sb_combine(L.out_wp, c->p_o, D_MODEL, SK_OUT, c->part_o, c->part_ml, c->nsplit, nb, st); }
+      { ProfScope ps(c, 1); LAUNCH(launch_skinny_gemm_sb_combine(L.out_wp, c->p_o, D_MODEL, SK_OUT, c->part_o, c->part_ml, c->nsplit, nb, st)); }
       {
         ProfScope ps(c, 1);
-        launch_skinny16_sb_ln(L.l1_wp, L.l1_b, c->xp4, D_FF, c->p_o, SK_OUT, L.out_b, hr, hw, L.n2_w, L.n2_b, nb, st);
+        LAUNCH(launch_skinny16_sb_ln(L.l1_wp, L.l1_b, c->xp4, D_FF, c->p_o, SK_OUT, L.out_b, hr, hw, L.n2_w, L.n2_b, nb, st));
         std::swap(hr, hw);
       }
       { ProfScope ps(c, 1); launch_skinny_gemm(L.l2_wp, c->xp4, c->p_o, D_MODEL, D_FF, SK_L2, st); }
     }
     {
       ProfScope ps(c, 1);
-      launch_skinny_gemm_sb_ln(c->pred_wp, c->p_logits, PRED_NPAD, SK_PRED, c->p_o, SK_L2, c->ar[NL - 1].l2_b, hr, nullptr,
-                               W(c, "ar_decoder.norm.weight"), W(c, "ar_decoder.norm.bias"), nb, st);
+      LAUNCH(launch_skinny_gemm_sb_ln(c->pred_wp, c->p_logits, PRED_NPAD, SK_PRED, c->p_o, SK_L2, c->ar[NL - 1].l2_b, hr, nullptr,
+                               W(c, "ar_decoder.norm.weight"), W(c, "ar_decoder.norm.bias"), nb, st));
     }
-    if (sa) launch_dec_sample(*sa, st);
+    if (sa) LAUNCH(launch_dec_sample(*sa, st));
     return;
   }
   for (int l = 0; l < NL; ++l) {
@@ -361,8 +366,8 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
     const bool fused = c->fuse_out && c->nsplit == 1;
     {
       ProfScope ps(c, 0);
-      launch_dec_attn(c->p_qkv, SK_QKV, L.in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax, c->slot_meta,
-                      c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, fused ? L.out_wh : nullptr, c->p_oh, st);
+      LAUNCH(launch_dec_attn(c->p_qkv, SK_QKV, L.in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax, c->slot_meta,
+                      c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, fused ? L.out_wh : nullptr, c->p_oh, st));
     }
     if (fused) {
       launch_dec_reduce_ln_pack(c->p_oh, N_HEAD, D_MODEL, L.out_b, c->dh, c->dh, L.n2_w, L.n2_b, c->xp, nb, st);
@@ -378,14 +383,27 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
     launch_dec_reduce_ln_pack(c->p_o, SK_L2, D_MODEL, L.l2_b, c->dh, c->dh, ng, nbp, c->xp, nb, st);
   }
   { ProfScope ps(c, 1); launch_skinny_gemm(c->pred_wp, c->xp, c->p_logits, PRED_NPAD, D_MODEL, SK_PRED, st); }
-  if (sa) launch_dec_sample(*sa, st);
+  if (sa) LAUNCH(launch_dec_sample(*sa, st));
+}
+
+// the decode kernels compile these split counts in (decode.hip); retuning one without instantiating it must not reach a GPU
+static_assert(SK_QKV == 4, "dec_attn_kernel<*, 4> sums four QKV slabs in its prologue");
+static_assert(SK_OUT == 4, "skinny16_sb_kernel<4> / dec_reduce_ln_pack<4> are the instantiated out_proj consumers");
+static_assert(SK_L2 == 8 || SK_L2 == 4, "skinny_gemm_sb_kernel<0, 8 | 4> are the instantiated linear2 consumers");
+static_assert(SK_PRED == 4 || SK_PRED == 2 || SK_PRED == 1, "dec_sample_kernel<4 | 2 | 1>");
+
+int launch_status(vx_ctx* c) {
+  if (!c->launch_fail) return VX_OK;
+  const char* what = c->launch_fail;
+  c->launch_fail = nullptr;
+  FAIL(VX_EINVAL, "kernel configuration not compiled into this library: %s", what);
 }
 
 int ar_step_run(vx_ctx* c, const SampleArgs* sa, const std::string& sig) {
   if (!c->cfg.use_graph || c->prof_on == 1 || !sa) {
     ar_step_launches(c, sa);
     HIPCHK(hipGetLastError());
-    return VX_OK;
+    return launch_status(c);
   }
   if (!c->graph_exec || c->graph_sig != sig) {
     if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
@@ -393,6 +411,7 @@ int ar_step_run(vx_ctx* c, const SampleArgs* sa, const std::string& sig) {
     HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     ar_step_launches(c, sa);
     HIPCHK(hipStreamEndCapture(c->stream, &g));
+    if (int e = launch_status(c)) { (void)hipGraphDestroy(g); return e; }      // an incomplete step must never be replayed
     HIPCHK(hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0));
     (void)hipGraphDestroy(g);
     c->graph_sig = sig;
@@ -405,7 +424,14 @@ int ar_step_run(vx_ctx* c, const SampleArgs* sa, const std::string& sig) {
 int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int nb, std::vector<int>& n_gen,
                 std::vector<int>& gen, int beams = 1) {
   const int nb_rows = nb;                            // rows of the caller's batch that this micro-batch prefills
-  if (int e = ar_prefill(c, b, r0, nb_rows, beams)) return e;
+  // a context whose prefills keep leaving the fp16 range runs them on the exact-fp32 kernels straight away (sticky fallback)
+  const bool direct_f32 = c->sticky_prefill_f32 && range_guarded(c);
+  if (direct_f32) {
+    ++c->st_fb_prefill; ++c->fb_total;
+    if (int e = ensure_f32_buffers(c)) return e;
+    F32Scope f32(c);
+    if (int e = ar_prefill(c, b, r0, nb_rows, beams)) return e;
+  } else if (int e = ar_prefill(c, b, r0, nb_rows, beams)) return e;
   const int ub = beams > 1 ? beams : b->batch;       // columns of the caller's uniforms: [steps][batch] or [steps][best_of]
   if (beams > 1) nb = beams;
   if (s->uniforms) {
@@ -431,9 +457,10 @@ int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int 
   auto first_sample = [&]() -> int {
     int flag = 0;
     HIPCHK(hipMemsetAsync(c->sum_logp, 0, MB * sizeof(float), c->stream));
-    launch_dec_sample(sa, c->stream);
+    LAUNCH(launch_dec_sample(sa, c->stream));
+    if (int e = launch_status(c)) return e;
     HIPCHK(hipMemcpyAsync(act.data(), c->active, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    if (range_guarded(c)) HIPCHK(hipMemcpyAsync(&flag, c->range_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (range_guarded(c) && !direct_f32) HIPCHK(hipMemcpyAsync(&flag, c->range_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     raised = flag != 0;
     any = std::any_of(act.begin(), act.end(), [](int v) { return v != 0; });
@@ -445,6 +472,7 @@ int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int 
     // Re-run the prefill on the exact-fp32 kernels (it resets the decode state) and sample the first token again.
     HIPCHK(hipMemsetAsync(c->range_flag, 0, sizeof(int), c->stream));
     ++c->st_fb_prefill; ++c->fb_total;
+    if (++c->fb_prefill_raises >= FB_STICKY_AFTER) c->sticky_prefill_f32 = true;
     if (int e = ensure_f32_buffers(c)) return e;
     {
       F32Scope f32(c);
@@ -565,6 +593,17 @@ int nar_generate_once(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::v
     }
     int* samples = c->imeta + o_samples + (long)st * sumT;
     launch_argmax_rows(c->flogits, AUDIO_VOCAB, (int)sumT, AUDIO_VOCAB, samples, c->stream);
+    if (st == 0 && c->fb_nar_raises > 0 && range_guarded(c)) {
+      // this context has left the fp16 range in a NAR phase before: look at the flag behind stage 0 already, so that an
+      // out-of-range model does not pay six more f16x2 stages before the fp32 re-run (costs one host sync; never in the common case)
+      int early = 0;
+      HIPCHK(hipMemcpyAsync(&early, c->range_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      if (early) {
+        HIPCHK(hipMemsetAsync(c->range_flag, 0, sizeof(int), c->stream));
+        return VX_RETRY_F32;
+      }
+    }
     if (st < N_Q - 2) {
       snprintf(nm, sizeof nm, "nar_audio_embeddings.%d.word_embeddings.weight", st + 1);
       launch_embed_accum(c->fyemb, mb.dev(o_gy), W(c, nm), samples, (int)sumT, c->stream);
@@ -584,9 +623,14 @@ int nar_generate_once(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::v
 
 int nar_generate(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::vector<int>& T, const int* codes0,
                  long codes0_stride, std::vector<int>& out_codes /* [7][sumT] */, long& sumT_out) {
-  int e = nar_generate_once(c, b, r0, nb, T, codes0, codes0_stride, out_codes, sumT_out);
-  if (e != VX_RETRY_F32) return e;
-  // an operand of one of the 7 stages left the fp16 range: the whole phase again on the exact-fp32 kernels (F32Scope)
+  int e = VX_RETRY_F32;
+  const bool direct_f32 = c->sticky_nar_f32 && range_guarded(c);          // sticky fallback (engine_ctx.h)
+  if (!direct_f32) {
+    e = nar_generate_once(c, b, r0, nb, T, codes0, codes0_stride, out_codes, sumT_out);
+    if (e != VX_RETRY_F32) return e;
+    if (++c->fb_nar_raises >= FB_STICKY_AFTER) c->sticky_nar_f32 = true;
+  }
+  // an operand of one of the 7 stages left the fp16 range: the whole phase (again) on the exact-fp32 kernels (F32Scope)
   ++c->st_fb_nar; ++c->fb_total;
   if ((e = ensure_f32_buffers(c))) return e;
   F32Scope f32(c);
@@ -673,9 +717,12 @@ int vx_ar_prefill(vx_ctx* c, const vx_batch* b) {
   HIPCHK(hipSetDevice(c->dev));
   if (int e = check_batch(c, b, c->mbr)) return e;
   c->st_fb_prefill = c->st_fb_nar = 0;
-  if (int e = ar_prefill(c, b, 0, b->batch)) return e;
-  bool raised = false;
-  if (int e = take_range_flag(c, &raised)) return e;       // syncs when the mode is guarded
+  bool raised = c->sticky_prefill_f32 && range_guarded(c);
+  if (!raised) {
+    if (int e = ar_prefill(c, b, 0, b->batch)) return e;
+    if (int e = take_range_flag(c, &raised)) return e;       // syncs when the mode is guarded
+    if (raised && ++c->fb_prefill_raises >= FB_STICKY_AFTER) c->sticky_prefill_f32 = true;
+  }
   if (raised) {
     ++c->st_fb_prefill; ++c->fb_total;
     if (int e = ensure_f32_buffers(c)) return e;
@@ -692,7 +739,8 @@ int vx_ar_logits(vx_ctx* c, float* out) {
   if (c->cur_batch <= 0) FAIL(VX_ESTATE, "no prefill has run");
   HIPCHK(hipSetDevice(c->dev));
   SampleArgs sa = make_sample_args(c, nullptr, 0, c->d_logits);
-  launch_dec_sample(sa, c->stream);
+  LAUNCH(launch_dec_sample(sa, c->stream));
+  if (int e = launch_status(c)) return e;
   HIPCHK(hipMemcpyAsync(out, c->d_logits, (size_t)c->cur_batch * AR_LOGITS * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return VX_OK;

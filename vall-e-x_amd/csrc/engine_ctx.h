@@ -42,6 +42,7 @@ struct ProfClass {
 
 constexpr int SK_QKV = 4, SK_OUT = 4, SK_L2 = 8, SK_PRED = 4;
 constexpr int PRED_NPAD = 1056;
+constexpr int FB_STICKY_AFTER = 2;
 
 }  // namespace vxe
 using namespace vxe;
@@ -52,6 +53,7 @@ struct vx_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev_t[3] = {nullptr, nullptr, nullptr};   // AR / NAR phase timing of vx_infer (created once, vx_create)
   std::string err;
+  const char* launch_fail = nullptr;   // a launcher refused a configuration that is not compiled in (set by LAUNCH, read by the ABI call)
   std::map<std::string, Tensor> w;
   bool finalized = false;
   std::vector<void*> allocs;
@@ -82,6 +84,11 @@ struct vx_ctx {
   unsigned long long* seed_dev = nullptr;   // seed of the counter-based sampler (device word: not part of the captured graph)
   int st_fb_prefill = 0, st_fb_nar = 0;     // phases of the last call that were re-run in fp32 (vx_last_fallbacks)
   long fb_total = 0;                        // ... since the context was created
+  // sticky fallback: a checkpoint whose operands leave the fp16 range on (nearly) every call would pay an f16x2 pass AND an fp32
+  // pass each time.  After FB_STICKY_AFTER raises of a phase kind that kind runs on the exact-fp32 kernels directly (still counted
+  // by vx_last_fallbacks); after the first raise the NAR phase polls the flag right behind stage 0 instead of behind stage 6.
+  int fb_prefill_raises = 0, fb_nar_raises = 0;
+  bool sticky_prefill_f32 = false, sticky_nar_f32 = false;
   unsigned short* fa3b = nullptr;  // second plane buffer: linear1 writes linear2's A planes straight from its epilogue (f16x2 mode)
   unsigned short* fa3 = nullptr;   // activation planes [2 or 3][M][K<=4096]
   unsigned short* pred_w3[N_Q - 1] = {};
@@ -95,6 +102,7 @@ struct vx_ctx {
   // decode arena
   float *kc = nullptr, *vc = nullptr;      // [NL][mbr*16][Tmax][64]
   float *dh = nullptr, *dh2 = nullptr, *xp = nullptr, *xp_att = nullptr, *xp4 = nullptr;
+  bool sb_chain = false;           // the current micro-batch decodes on the small-batch chain (set by ar_prefill)
   bool sb_fuse = true;             // <= SB_ROWS rows: reduce+LN / combine folded into the consuming GEMM (VX_SB_FUSE=0: the general chain)
   float *p_qkv = nullptr, *p_o = nullptr, *p_oh = nullptr, *p_logits = nullptr, *part_o = nullptr, *part_ml = nullptr;
   std::map<const unsigned short*, int> w_shift;   // f16x2: power-of-two scale exponent of every weight's planes
@@ -162,6 +170,12 @@ struct vx_ctx {
     return (code);                              \
   } while (0)
 
+// launchers that compile a split count in return false instead of launching an uninstantiated configuration
+#define LAUNCH(call)                                      \
+  do {                                                    \
+    if (!(call) && !c->launch_fail) c->launch_fail = #call; \
+  } while (0)
+
 namespace vxe {
 
 template <typename T>
@@ -226,6 +240,7 @@ int take_range_flag(vx_ctx* c, bool* raised);
 int check_batch(vx_ctx* c, const vx_batch* b, int max_rows);
 SampleArgs make_sample_args(vx_ctx* c, const vx_sampling* s, int commit, float* logits_out);
 void ar_step_launches(vx_ctx* c, const SampleArgs* sa);
+int launch_status(vx_ctx* c);      // VX_EINVAL (+ message) if a launcher refused since the last check
 
 struct F32Scope {            // the full-sequence path on the exact-fp32 kernels for the lifetime of the object
   vx_ctx* c;

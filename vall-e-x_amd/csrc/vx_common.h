@@ -149,15 +149,19 @@ void launch_skinny16_relu_pack(const float* W16, const float* xp, const float* b
                                hipStream_t s);
 // small batches (<= SB_ROWS rows): the consumer GEMM computes its own input rows in its prologue (decode.hip)
 constexpr int SB_ROWS = 4;
+// The launchers below that return bool compile a producer's split count into the kernel: false = that configuration is not
+// instantiated and NOTHING was launched (the engine turns it into VX_EINVAL; a library must never abort() its host process).
+// sb_chain_supported: may the small-batch chain run with these split counts?  (otherwise the engine takes the general chain)
+bool sb_chain_supported(int sk_l2, int sk_out, int nsplit, int batch);
 // partial_out[ks][b][n] = sum_k LN(resid[b] + sum_ks' partial_in[ks'][b] + bias)[k] W[n][k]   (K = 1024); workgroup 0 writes h_out
-void launch_skinny_gemm_sb_ln(const float* Wp, float* partial_out, int Npad, int splitk, const float* partial_in, int sk_in,
+bool launch_skinny_gemm_sb_ln(const float* Wp, float* partial_out, int Npad, int splitk, const float* partial_in, int sk_in,
                               const float* bias, const float* resid, float* h_out, const float* g, const float* b, int batch,
                               hipStream_t s);
 // the same GEMM on the combine of dec_attn's context-split partials (out_proj, K = 1024)
-void launch_skinny_gemm_sb_combine(const float* Wp, float* partial_out, int Npad, int splitk, const float* part_o, const float* part_ml,
+bool launch_skinny_gemm_sb_combine(const float* Wp, float* partial_out, int Npad, int splitk, const float* part_o, const float* part_ml,
                                    int nsplit, int batch, hipStream_t s);
 // linear1 (bias + ReLU + pack fused, 16-row tiles) on LN(resid + sum of the out_proj slabs + pbias)
-void launch_skinny16_sb_ln(const float* W16, const float* bias, float* xp_out, int N, const float* partial_in, int sk_in,
+bool launch_skinny16_sb_ln(const float* W16, const float* bias, float* xp_out, int N, const float* partial_in, int sk_in,
                            const float* pbias, const float* resid, float* h_out, const float* g, const float* b, int batch,
                            hipStream_t s);
 // h[b] = tab[tok[b]] + alpha*pe[pos[b]] ; xp = pack(LN(h))  -- start of a decode step
@@ -167,7 +171,7 @@ void launch_dec_embed_ln_pack(const int* tok, const int* pos, const float* tab, 
 // wo_heads != null and nsplit == 1: out_proj fused into the epilogue, per-head partial slabs out_heads[h][MB][1024]
 // slot_meta [batch][4] = {row, cached rows incl. the new token, active, -} per launch slot (kept current by dec_sample /
 // dec_force_token through slot_of[row])
-void launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias, float* kc, float* vc, int Tmax,
+bool launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias, float* kc, float* vc, int Tmax,
                      const int* slot_meta, float* xp_out, float* part_o, float* part_ml, int nsplit, int batch,
                      const float* wo_heads, float* out_heads, hipStream_t s);
 void launch_pack_wo_heads(const float* W, float* out, hipStream_t s);
@@ -190,7 +194,7 @@ struct SampleArgs {
   const float* emb_tab; const float* emb_alpha; const float* pe; const float* ln_g; const float* ln_b;
   float* emb_h; float* emb_xp;
 };
-void launch_dec_sample(const SampleArgs& a, hipStream_t s);
+bool launch_dec_sample(const SampleArgs& a, hipStream_t s);
 #ifdef VX_DEV_PROBES
 void dev_read_gemm_stamps(unsigned long long* out);     // gemm_f16x2.hip: shader-clock stamps around two k-steps, [256][16]
 // development timeline of the decode kernels (decode.hip: vx_stamps[8][512][8], 100 MHz wall-clock ticks)

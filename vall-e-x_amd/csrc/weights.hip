@@ -128,6 +128,9 @@ int vx_finalize_weights(vx_ctx* c) {
   // in f16x2 mode the attention output and the FFN hidden activations only ever exist as operand planes (fa3 / fa3b)
   if (!(c->gemm_mode == 0 && c->attn_x3) && (e = dev_alloc(c, &c->fatt, (size_t)M * d))) return e;
   if (c->gemm_mode != 0 && (e = dev_alloc(c, &c->fffn, (size_t)M * f))) return e;
+  // the fp32 activations of the range-guard fallback: allocated here, not inside the first request that falls back (a
+  // synchronising hipMalloc of hundreds of MB in the timed path that could fail after finalize succeeded)
+  if (range_guarded(c) && (e = ensure_f32_buffers(c))) return e;
   if ((e = dev_alloc(c, &c->fyemb, (size_t)M * d))) return e;
   if ((e = dev_alloc(c, &c->flogits, (size_t)((long)c->mbr * c->cfg.max_new + 128) * AUDIO_VOCAB))) return e;
   c->imeta_cap = std::max(M * 24, (long)c->cfg.max_batch * c->cfg.max_new * 12) + 65536;

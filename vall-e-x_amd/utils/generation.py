@@ -65,6 +65,19 @@ class VocosHIP:
         return torch.from_numpy(out) if torch is not None and isinstance(out, np.ndarray) else out
 
 
+def _torch_load(path):
+    """torch.load(path, map_location='cpu') as the reference does (utils/generation.py:79).  torch >= 2.6 defaults to
+    weights_only=True, which is what a checkpoint of plain tensors needs; the published vallex-checkpoint.pt may carry pickled
+    training state next to "model" -- then (and only then) the permissive loader is used, like the reference's torch 2.0 did."""
+    try:
+        return torch.load(path, map_location="cpu")
+    except Exception as e:                                   # pickle.UnpicklingError: weights-only refused a global
+        if "weights_only" not in str(e) and "Weights only" not in str(e):
+            raise
+        logging.warning(f"{path}: not loadable with weights_only=True ({type(e).__name__}); loading it like torch 2.0 did")
+        return torch.load(path, map_location="cpu", weights_only=False)
+
+
 def preload_models(checkpoint: Optional[str] = None, vocos_checkpoint: Optional[str] = None, state_dict=None,
                    vocos_state_dict=None, num_layers: int = NUM_LAYERS, **engine_opts):
     """Build the engine and load weights.  With no arguments behaves like the reference (expects
@@ -75,14 +88,14 @@ def preload_models(checkpoint: Optional[str] = None, vocos_checkpoint: Optional[
         if not os.path.exists(path):
             raise FileNotFoundError(f"{path} not found (the reference downloads it, utils/generation.py:53-65; "
                                     "no network here): pass checkpoint= or state_dict=")
-        state_dict = torch.load(path, map_location="cpu")["model"]                 # :79-83
+        state_dict = _torch_load(path)["model"]                                   # :79-83
     m = VALLE(N_DIM, NUM_HEAD, num_layers, norm_first=True, add_prenet=False, prefix_mode=PREFIX_MODE,
               share_embedding=True, nar_scale_factor=1.0, prepend_bos=True, num_quantizers=NUM_QUANTIZERS,
               **{"engine_" + k: v for k, v in engine_opts.items()})
     m.to(device).load_state_dict(state_dict, strict=True)
     m.eval()
     if vocos_state_dict is None and vocos_checkpoint is not None:
-        vocos_state_dict = torch.load(vocos_checkpoint, map_location="cpu")
+        vocos_state_dict = _torch_load(vocos_checkpoint)
     if vocos_state_dict is not None:
         m.load_vocos_state_dict(vocos_state_dict)
     model = m
@@ -228,11 +241,9 @@ def generate_audio_from_long_text(text, prompt=None, language="auto", accent="no
     """utils/generation.py:155-276.  `text` may also be a list of sentences / id arrays (pre-split)."""
     if model is None or vocos is None:
         raise RuntimeError("call preload_models() first")
-    if mode not in ("fixed-prompt", "sliding-window"):
-        raise ValueError(f"No such mode {mode}")                       # :276
     if prompt is None or prompt == "":
         prompt = None
-        mode = "sliding-window"                                        # :162-163
+        mode = "sliding-window"                                        # :162-163: overrides ANY mode, also an unknown one
     if isinstance(text, str):
         if sentence_splitter is None:
             raise RuntimeError("no sentence splitter configured (the reference uses utils/sentence_cutter.py): set "
@@ -248,6 +259,10 @@ def generate_audio_from_long_text(text, prompt=None, language="auto", accent="no
         audio_prompts = np.zeros([1, 0, NUM_QUANTIZERS], np.int32)
         text_prompts = np.zeros([1, 0], np.int32)
         lang_pr = None
+    # the reference only looks at `mode` here, after the override, the sentence split, the language detection and the prompt
+    # lookup (its if / elif / else ends in the raise, utils/generation.py:197,229,275-276) -- same order of errors
+    if mode not in ("fixed-prompt", "sliding-window"):
+        raise ValueError(f"No such mode {mode}")                       # :276
     original = (audio_prompts, text_prompts)
     chunks = []
     for sent in sentences:

@@ -45,7 +45,9 @@ def resample_sinc_hann(wav: np.ndarray, orig_freq: int, new_freq: int, lowpass_f
     base = min(o, n) * rolloff
     width = math.ceil(lowpass_filter_width * o / base)
     idx = torch.arange(-width, width + o, dtype=torch.float64)[None, None] / o
-    t = (torch.arange(0, -n, -1, dtype=torch.float64)[:, None, None] / n + idx) * base
+    # torchaudio's _get_sinc_resample_kernel with dtype=None: the phase term is an int64 arange divided in fp32 and promoted to
+    # fp64 when idx is added -- reproduced so that the fp32 taps are the package's bit for bit
+    t = ((torch.arange(0, -n, -1).to(torch.float32) / n).to(torch.float64)[:, None, None] + idx) * base
     t = t.clamp_(-lowpass_filter_width, lowpass_filter_width)
     window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
     t = t * math.pi
