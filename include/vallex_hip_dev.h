@@ -16,7 +16,8 @@ extern "C" {
 /* ---- per-class event timing --------------------------------------------------------------------------------
  * HIP-event timing of kernel classes on the context's own stream (bench.py roofline leg).
  * which: 0 = dec_attn (KV streaming), 1 = skinny GEMMs, 2 = transformer projections (full-sequence GEMMs), 3 = full-seq
- * attention, 4 = the fp32 GEMMs of the Vocos / EnCodec heads.
+ * attention, 4 = the fp32 GEMMs of the Vocos / EnCodec heads, 5 = the LSTM recurrences of the EnCodec decoder (one event pair
+ * per layer around its T dependent steps; `algo_bytes` of this class counts the steps).
  * vx_prof_enable(1) makes the AR step run un-graphed with an event pair around each launch of every class. */
 int vx_prof_enable(vx_ctx* ctx, int32_t on);
 int vx_prof_get(vx_ctx* ctx, int32_t which, double* total_ms, int64_t* launches, double* algo_bytes);

@@ -74,3 +74,32 @@ def test_bench_contexts_mode_stub():
     assert j["steps"] == 4 and j["config"]["contexts_per_gpu"] == 2 and j["config"]["rows_in_flight_per_gpu"] == 8
     assert abs(j["value"] * j["ms_per_step"] * 4 / 1e3 - 2 * 2 * 4 * 10 / 75.0) < 1e-2        # every pass of every context counted
     assert "not the headline" in j["note"]
+
+
+def test_bench_gpus8_stub_is_baseline_config_4():
+    """the driver's 8-GPU call shape (BASELINE config 4: 256 rows, 32 per GPU): eight self-started ranks, ONE JSON line, eight
+    per_rank entries, rows 0..255 sharded contiguously and all gathered after the timed region; stub engine over gloo"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--frames", "10",
+                        "--stub"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 8 and j["scaling"] == "weak" and j["config"]["rows_per_gpu"] == 32 and j["config"]["rows_total"] == 256
+    pr = sorted(j["per_rank"], key=lambda d: d["rank"])
+    assert [d["rows"] for d in pr] == [[32 * r, 32 * r + 32] for r in range(8)]
+    assert j["rows_gathered"] == 256
+    assert "parallelism" in j["config"] and "replicas x8" in j["config"]["parallelism"]
+    # eight ranks on one host do not oversubscribe it: every rank caps its host threads at cores // world
+    assert "host threads per rank" in r.stderr
+
+
+def test_bench_refuses_ranks_without_a_gpu_each():
+    """--gpus N with fewer than N visible devices is not a scaling point: fail fast and say why (unless --allow-shared-gpu)"""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("this box has a GPU per rank")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "one rank per GPU is required" in r.stderr and "--allow-shared-gpu" in r.stderr

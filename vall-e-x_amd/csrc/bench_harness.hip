@@ -35,7 +35,7 @@ int vx_prof_reset(vx_ctx* c) {
 }
 
 int vx_prof_get(vx_ctx* c, int32_t which, double* total_ms, int64_t* launches, double* algo_bytes) {
-  if (!c || which < 0 || which > 4) return VX_EINVAL;
+  if (!c || which < 0 || which > 5) return VX_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
   HIPCHK(hipStreamSynchronize(c->stream));
   ProfClass& p = c->prof[which];

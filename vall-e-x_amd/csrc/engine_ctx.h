@@ -126,7 +126,7 @@ struct vx_ctx {
 
   // profiling / stats
   int prof_on = 0;                 // 0 off, 1 every class (AR step runs eagerly), 2 full-sequence classes only
-  ProfClass prof[5];
+  ProfClass prof[6];             // 0 dec_attn, 1 skinny GEMMs, 2 projections, 3 full-seq attention, 4 vocoder GEMMs, 5 LSTM recurrences
   int64_t st_steps = 0, st_frames = 0;
   int st_truncated = 0;            // rows of the last vx_infer cut by the arena (max_new) before the reference's stop rule
   double st_ar_ms = 0, st_nar_ms = 0;

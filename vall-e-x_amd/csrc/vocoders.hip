@@ -145,9 +145,13 @@ int vx_encodec_decode(vx_ctx* c, const int64_t* codes, int32_t codes_stride, con
       HIPCHK(hipMemsetAsync(c->ec_hp, 0, (size_t)MB * 512 * sizeof(float), st));
       HIPCHK(hipMemsetAsync(c->ec_c, 0, (size_t)MB * 512 * sizeof(float), st));
       float* yout = l == 0 ? c->ec_y1 : c->ec_y2;
-      for (int t = 0; t < maxT; ++t) {
-        launch_skinny_gemm(c->ec_whh_p[l], c->ec_hp, c->ec_pg, 2048, 512, 2, st);
-        launch_lstm_cell(c->ec_pg, 2, c->ec_xg, d_off, d_len, t, c->ec_c, c->ec_hp, yout, l == 1 ? c->ec_x0 : nullptr, nb, st);
+      {
+        ProfScope ps(c, 5);                        // the recurrence of one layer: maxT dependent (GEMV-like GEMM | cell) pairs
+        if (c->prof_on) c->prof[5].bytes += (double)maxT;        // "bytes" of class 5 = recurrence steps
+        for (int t = 0; t < maxT; ++t) {
+          launch_skinny_gemm(c->ec_whh_p[l], c->ec_hp, c->ec_pg, 2048, 512, 2, st);
+          launch_lstm_cell(c->ec_pg, 2, c->ec_xg, d_off, d_len, t, c->ec_c, c->ec_hp, yout, l == 1 ? c->ec_x0 : nullptr, nb, st);
+        }
       }
       lin = yout;
     }
