@@ -23,6 +23,8 @@
 // Structure of the tile loop: three LDS buffers (tile t: V, tile t+1: K, tile t+2: being written) and ONE barrier per tile;
 // phase 1 = 12 slots of [1 QK^T MFMA of tile t+1 | a slice of tile t's softmax], phase 2 = 12 slots of [1 PV MFMA of tile t | a
 // slice of the splits of P, of the staged K and of the staged V + their LDS stores]; every slice is pinned in its slot.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "vx_common.h"
@@ -93,13 +95,28 @@ __device__ __forceinline__ f32x2 exp_s2(f32x2 x) {
 
 }  // namespace
 
-// The product kernel (no timing-probe variants here; the probes of attn_full_x3.hip describe the same structure).
+// PRIO: wave-priority policy (guide T5; two 4-wave workgroups share a CU = two independent waves per SIMD whose MFMAs compete with
+// the partner's softmax / split VALU):  0 none;  1 s_setprio(1) around every MFMA of the tile loop;  2 static: the workgroups
+// with an odd block id run at priority 1 throughout;  3 priority 1 through phase 2 (the PV products + operand splits) only.
+// The product instantiates ONE value (VX_ATTN_PRIO below); tools builds (-DVX_DEV_PROBES) instantiate all four for A/B
+// (vx_bench_attn variants 20..23).  Results do not depend on it.
+#ifndef VX_ATTN_PRIO
+#define VX_ATTN_PRIO 0
+#endif
+template <int PRIO>
 __global__ __launch_bounds__(256, 2) void attn_full_h2_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                              const int* __restrict__ seq_off,
                                                              const int* __restrict__ seq_len,
                                                              const int* __restrict__ prefix_len, int nqb,
                                                              unsigned short* __restrict__ planes, long plane_stride,
-                                                             int* __restrict__ range_flag) {
+                                                             int* __restrict__ range_flag,
+                                                             const int* __restrict__ q_first,
+                                                             const int* __restrict__ c_off) {
+  // q_first / c_off (planes mode only, optional): ROW TRIMMING for a layer whose output is only needed for the rows
+  // [q_first[b], len) of every sequence (the last decoder layer of a NAR stage: only generated frames reach a predict layer,
+  // models/vallex.py:672-679).  Query blocks that lie entirely before q_first[b] are skipped, and the output planes are written
+  // COMPACTED: sequence-local query qi >= q_first[b] lands in plane row c_off[b] + qi - q_first[b].  Keys / values are still
+  // all of the sequence.  Every stored value is computed exactly as without trimming.
   __shared__ __attribute__((aligned(16))) unsigned char Kp[3][2][KP_SZ];   // [buffer][plane: head, tail]
   __shared__ __attribute__((aligned(16))) unsigned char Vt[3][2][VT_SZ];
 
@@ -110,6 +127,11 @@ __global__ __launch_bounds__(256, 2) void attn_full_h2_kernel(const float* __res
   const int b = u / N_HEAD, h = u - b * N_HEAD, q0 = (rem >> 3) * QB;
   const int len = seq_len[b];
   if (q0 >= len) return;
+  const int qf = q_first ? q_first[b] : 0;
+  if (q0 + QB <= qf) return;                                    // no query of this block is needed
+  if constexpr (PRIO == 2) {                                    // s_setprio ignores EXEC: the guard must be scalar (guide T5)
+    if (__builtin_amdgcn_readfirstlane((int)blockIdx.x) & 1) __builtin_amdgcn_s_setprio(1);
+  }
   const long row0 = seq_off[b];
   const int S = prefix_len ? prefix_len[b] : 0x7fffffff;       // keys < S are visible to everyone
   const bool causal = prefix_len != nullptr;
@@ -248,7 +270,9 @@ __global__ __launch_bounds__(256, 2) void attn_full_h2_kernel(const float* __res
       constexpr int pb = j == 1 ? 1 : 0;                       // plane of Q
       if constexpr (j == 0 && s < 3) kfrag(nxt, s + 1, (s & 1) ? kfa : kfb);   // next k-step's fragments
       if constexpr (i == 9) vfrag(cur, 0, v0, v1);
+      if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
       sA = __builtin_amdgcn_mfma_f32_32x32x16_f16((s & 1) ? kfb[pa] : kfa[pa], qp[s][pb], i ? sA : zero, 0, 0, 0);
+      if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
       if constexpr (i < 2) {                                   // visibility, 8 keys per slot (interior tiles skip it)
         if (need_mask) {
           float mv[8];
@@ -312,7 +336,10 @@ __global__ __launch_bounds__(256, 2) void attn_full_h2_kernel(const float* __res
       if constexpr (i == 1) vfrag(cur, 1, w0, w1);
       const f16x8 pf = __builtin_bit_cast(f16x8, u32x4{pw[s][pb][0], pw[s][pb][1], pw[s][pb][2], pw[s][pb][3]});
       const f16x8 vf = s ? (half ? w1[pa] : w0[pa]) : (half ? v1[pa] : v0[pa]);
+      if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(1);
+      if constexpr (PRIO == 3 && i == 0) __builtin_amdgcn_s_setprio(1);
       o[half] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[half], 0, 0, 0);
+      if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(0);
       if constexpr (i < 4) {
         split_p(1, i);
       } else if constexpr (i < 8) {
@@ -326,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void attn_full_h2_kernel(const float* __res
       }
       __builtin_amdgcn_sched_barrier(0);
     });
+    if constexpr (PRIO == 3) __builtin_amdgcn_s_setprio(0);
     // One barrier per tile: buffer `wr` (tile t+2; past the last tile a stale copy nobody reads) was last read in
     // iteration t-1, is written above, and is first read below / in iteration t+1.
     __syncthreads();
@@ -343,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void attn_full_h2_kernel(const float* __res
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  if (qi < len) {
+  if (qi < len && qi >= qf) {
     const float inv = V_INV / l_tot;                           // O' / l' = 2^5 O / l
     bool nonfinite = false;                                    // an operand head that did not fit fp16 (inf) ends up here as NaN
     if (!planes) {
@@ -361,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void attn_full_h2_kernel(const float* __res
       // the attention output only feeds out_proj: write it as that GEMM's f16x2 A planes (tile-major, K = 1024; the 32 dims of
       // `half` are one K tile, index 2 h + half).  Lanes l and l ^ 32 hold complementary 4-dim halves of every 8-dim group and
       // trade them, so each lane stores 16 contiguous bytes per plane (same scheme as the GEMM's plane epilogue).
-      const long row = row0 + qi;
+      const long row = c_off ? (long)c_off[b] + (qi - qf) : row0 + qi;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         unsigned hw[4][2], tw[4][2];
@@ -402,11 +430,24 @@ __global__ __launch_bounds__(256, 2) void attn_full_h2_kernel(const float* __res
 }
 
 void launch_attn_full_h2(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
-                         int batch, int max_len, hipStream_t s, unsigned short* planes, long plane_stride, int* range_flag) {
+                         int batch, int max_len, hipStream_t s, unsigned short* planes, long plane_stride, int* range_flag,
+                         int prio, const int* q_first, const int* c_off) {
   if (batch <= 0 || max_len <= 0) return;
   const int nqb = (max_len + QB - 1) / QB;                   // batch * N_HEAD is a multiple of 8 (16 heads)
-  hipLaunchKernelGGL(attn_full_h2_kernel, dim3(nqb * N_HEAD * batch), dim3(256), 0, s, qkv, out, seq_off, seq_len, prefix_len,
-                     nqb, planes, plane_stride, range_flag);
+  const dim3 grid(nqb * N_HEAD * batch), block(256);
+#define VX_ATTN_H2_GO(P) hipLaunchKernelGGL(attn_full_h2_kernel<P>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, planes, plane_stride, range_flag, planes ? q_first : nullptr, planes ? c_off : nullptr)
+#ifdef VX_DEV_PROBES
+  static const int env_prio = [] { const char* e = getenv("VX_ATTN_PRIO_RT"); return e ? atoi(e) : -1; }();
+  const int p = prio >= 0 ? prio : (env_prio >= 0 ? env_prio : VX_ATTN_PRIO);
+  if (p == 1) VX_ATTN_H2_GO(1);
+  else if (p == 2) VX_ATTN_H2_GO(2);
+  else if (p == 3) VX_ATTN_H2_GO(3);
+  else VX_ATTN_H2_GO(0);
+#else
+  (void)prio;
+  VX_ATTN_H2_GO(VX_ATTN_PRIO);
+#endif
+#undef VX_ATTN_H2_GO
 }
 
 }  // namespace vx

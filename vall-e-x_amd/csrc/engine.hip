@@ -53,7 +53,7 @@ void gemm(vx_ctx* c, const float* A, int lda, const float* Wt, int ldw, const fl
 // GEMM's A planes (K = N) instead of fp32 rows (C may then be null).
 void proj(vx_ctx* c, const float* A, int lda, const float* Wf, const unsigned short* W3, const float* bias,
           const float* resid, int ldr, float* C, int ldc, long M, int N, int K, int act, const int* gather = nullptr,
-          const unsigned short* a_pre = nullptr, unsigned short* out_pl = nullptr) {
+          const unsigned short* a_pre = nullptr, unsigned short* out_pl = nullptr, const int* resid_rows = nullptr) {
   if (c->gemm_mode == 2 || !W3) {
     gemm(c, A, lda, Wf, K, bias, resid, ldr, nullptr, C, ldc, M, N, K, act, gather, 2);
     return;
@@ -68,6 +68,7 @@ void proj(vx_ctx* c, const float* A, int lda, const float* Wf, const unsigned sh
   g.bias = bias; g.resid = resid; g.ldr = ldr;
   g.colscale = nullptr; g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.act = act;
   g.out_planes = out_pl; g.out_plane = out_pl ? h2_plane(M, N, H2_TILE_A) : 0; g.range_flag = c->range_flag;
+  g.resid_rows = resid_rows;                     // f16x2 kernel only (the one mode that trims rows)
   if (c->gemm_mode == 0) g.descale = ldexpf(1.0f, -(H2_ACT_SHIFT + c->w_shift.at(W3)));
   ProfScope ps(c, 2);
   if (c->prof_on) c->prof[2].bytes += 2.0 * (double)M * N * K;
@@ -76,10 +77,23 @@ void proj(vx_ctx* c, const float* A, int lda, const float* Wf, const unsigned sh
   else launch_gemm_bf16x3(g, c->stream);
 }
 
+// Row trimming of the LAST decoder layer of a NAR stage (f16x2 mode): only the generated frames of every sequence reach a predict
+// layer (models/vallex.py:672-679), so behind the K / V projection -- which attention needs for ALL rows -- the layer only has to
+// produce those rows: attention queries, out_proj, norm2 and the FFN run on the Mc = sum T_b compacted rows.  Every op of the
+// block treats rows independently, so each kept row goes through exactly the arithmetic it would see untrimmed: same ids, same
+// logits, bit for bit.  The compacted residual stream lives in c->fxn (unused in f16x2 mode otherwise).
+struct Trim {
+  long Mc;               // kept rows
+  const int* q_first;    // [batch] first kept sequence-local row (S + Tp)
+  const int* c_off;      // [batch] first compacted row of the sequence
+  const int* rows;       // [Mc] packed row of every compacted row (residual gather)
+  double attn_flops;     // 4 * T_b * L_b * 1024 summed: the queries that are still computed
+};
+
 // one pre-norm block on packed rows (modules/transformer.py:296-302 / :337-347) -- shared by AR prefill and NAR
 int full_layer(vx_ctx* c, const LayerW& L, long M, const int* seq_off, const int* seq_len, const int* prefix_len,
                int batch, int max_len, const float* ada1, const float* ada2, float* kcl, float* vcl,
-               const int* row_b, const int* row_t, double attn_flops) {
+               const int* row_b, const int* row_t, double attn_flops, const Trim* tr = nullptr) {
   // f16x2 mode: every producer of a GEMM operand (the two LayerNorms, the attention, linear1's epilogue) writes the operand
   // planes itself -- no fp32 round trip of the normalised / attended / hidden activations and no split pass on any edge.
   const bool pl = c->gemm_mode == 0;
@@ -90,6 +104,23 @@ int full_layer(vx_ctx* c, const LayerW& L, long M, const int* seq_off, const int
        pl ? c->fa3 : nullptr);
   if (kcl) launch_kv_scatter(c->fqkv, row_b, row_t, (int)M, kcl, vcl, c->Tmax, c->stream);
   const bool att_pl = pl && c->attn_x3;
+  if (tr) {                                        // caller guarantees f16x2 projections + f16x2 attention
+    const long plc = h2_plane(tr->Mc, D_MODEL, H2_TILE_A);
+    {
+      ProfScope ps(c, 3);
+      if (c->prof_on) c->prof[3].bytes += tr->attn_flops;
+      launch_attn_full_h2(c->fqkv, nullptr, seq_off, seq_len, prefix_len, batch, max_len, c->stream, c->fa3, plc, c->range_flag, -1,
+                          tr->q_first, tr->c_off);
+    }
+    // x' = x[kept rows] + out_proj(attention): residual read through the row map, result compacted in fxn
+    proj(c, nullptr, D_MODEL, L.out_w, L.out_w3, L.out_b, c->fx, D_MODEL, c->fxn, D_MODEL, tr->Mc, D_MODEL, D_MODEL, ACT_NONE, nullptr,
+         c->fa3, nullptr, tr->rows);
+    launch_layernorm(c->fxn, D_MODEL, nullptr, D_MODEL, (int)tr->Mc, D_MODEL, LN_EPS, L.n2_w, L.n2_b, ada2, ada2 ? ada2 + D_MODEL : nullptr,
+                     c->stream, c->fa3, plc, c->range_flag);
+    proj(c, nullptr, D_MODEL, L.l1_w, L.l1_w3, L.l1_b, nullptr, 0, nullptr, D_FF, tr->Mc, D_FF, D_MODEL, ACT_RELU, nullptr, c->fa3, c->fa3b);
+    proj(c, nullptr, D_FF, L.l2_w, L.l2_w3, L.l2_b, c->fxn, D_MODEL, c->fxn, D_MODEL, tr->Mc, D_MODEL, D_FF, ACT_NONE, nullptr, c->fa3b);
+    return VX_OK;
+  }
   {
     ProfScope ps(c, 3);
     if (c->prof_on) c->prof[3].bytes += attn_flops;
@@ -246,9 +277,10 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
   c->nsplit = std::max(1, std::min(16, 512 / (nrows * N_HEAD)));
   // the small-batch chain compiles the split counts in (decode.hip): taken only for a combination that is instantiated
   c->sb_chain = false;
+  c->hc_chain = c->mid_fuse && c->nsplit > 1 && hc_chain_supported(SK_OUT, c->nsplit);
   if (c->sb_fuse && nrows <= SB_ROWS) {
     const int ns = nrows <= 2 ? 16 : 8;
-    if (sb_chain_supported(SK_L2, SK_OUT, ns, nrows)) { c->nsplit = ns; c->sb_chain = true; }
+    if (sb_chain_supported(SK_L2, SK_OUT, ns, nrows)) { c->nsplit = ns; c->sb_chain = true; c->hc_chain = false; }
   }
 
   launch_embed_rows(c->fx, mb.dev(o_dt), W(c, "ar_text_embedding.word_embeddings.weight"), mb.dev(o_it),
@@ -372,8 +404,13 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
     if (fused) {
       launch_dec_reduce_ln_pack(c->p_oh, N_HEAD, D_MODEL, L.out_b, c->dh, c->dh, L.n2_w, L.n2_b, c->xp, nb, st);
     } else {
-      if (c->nsplit > 1) launch_dec_attn_combine(c->part_o, c->part_ml, c->nsplit, c->active, c->xp_att, nb, st);
-      { ProfScope ps(c, 1); launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, st); }
+      if (c->hc_chain) {      // 5 .. 16 rows: the combine runs in the out_proj GEMM's prologue, per wave = per head (decode.hip)
+        ProfScope ps(c, 1);
+        LAUNCH(launch_skinny_gemm_hc(L.out_wp, c->p_o, SK_OUT, c->part_o, c->part_ml, c->nsplit, nb, st));
+      } else {
+        if (c->nsplit > 1) launch_dec_attn_combine(c->part_o, c->part_ml, c->nsplit, c->active, c->xp_att, nb, st);
+        { ProfScope ps(c, 1); launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, st); }
+      }
       launch_dec_reduce_ln_pack(c->p_o, SK_OUT, D_MODEL, L.out_b, c->dh, c->dh, L.n2_w, L.n2_b, c->xp, nb, st);
     }
     { ProfScope ps(c, 1); launch_skinny16_relu_pack(L.l1_wp, c->xp, L.l1_b, c->xp4, D_FF, D_MODEL, st); }
@@ -481,7 +518,7 @@ int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int 
     }
   }
   char sig[160];
-  snprintf(sig, sizeof sig, "b%d ns%d k%d t%a u%d f%d l%d", nb, c->nsplit, sa.top_k, sa.temperature,
+  snprintf(sig, sizeof sig, "b%d ns%d c%d%d k%d t%a u%d f%d l%d", nb, c->nsplit, (int)c->sb_chain, (int)c->hc_chain, sa.top_k, sa.temperature,
            sa.uniforms != nullptr, sa.force_eos_at, sa.sum_logp != nullptr);
   const int sync_every = s->sync_every > 0 ? s->sync_every : 8;
   // with a forced EOS every row is inactive after force_eos_at steps: do not run on to the next host poll
@@ -517,12 +554,15 @@ constexpr int VX_RETRY_F32 = 1;      // internal: the phase raised the f16x2 ran
 int nar_generate_once(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::vector<int>& T, const int* codes0,
                       long codes0_stride, std::vector<int>& out_codes /* [7][sumT] */, long& sumT_out) {
   const int NL = c->NL;
-  std::vector<int> seq_off(nb), seq_len(nb), dst_t, id_t, lang_t, pos_t, ycodes, ynj, ydst, ypos, gen_rows, gen_y;
+  std::vector<int> seq_off(nb), seq_len(nb), dst_t, id_t, lang_t, pos_t, ycodes, ynj, ydst, ypos, gen_rows, gen_y, q_first(nb), c_off(nb);
   long M = 0, Y = 0, sumT = 0;
   int max_len = 0;
+  double trim_attn_flops = 0;
   for (int i = 0; i < nb; ++i) {
     const int r = r0 + i, S = b->text_lens[r], Tp = b->prompt_lens[r];
     seq_off[i] = (int)M; seq_len[i] = S + Tp + T[i];
+    q_first[i] = S + Tp; c_off[i] = (int)sumT;
+    trim_attn_flops += 4.0 * T[i] * (double)seq_len[i] * D_MODEL;
     max_len = std::max(max_len, seq_len[i]);
     for (int s = 0; s < S; ++s) {
       dst_t.push_back((int)M + s);
@@ -553,7 +593,7 @@ int nar_generate_once(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::v
   MetaBuilder mb(c);
   const long o_off = mb.add(seq_off), o_len = mb.add(seq_len), o_dt = mb.add(dst_t), o_it = mb.add(id_t),
              o_lt = mb.add(lang_t), o_pt = mb.add(pos_t), o_yc = mb.add(ycodes), o_nj = mb.add(ynj), o_yd = mb.add(ydst),
-             o_yp = mb.add(ypos), o_gr = mb.add(gen_rows), o_gy = mb.add(gen_y);
+             o_yp = mb.add(ypos), o_gr = mb.add(gen_rows), o_gy = mb.add(gen_y), o_qf = mb.add(q_first), o_co = mb.add(c_off);
   std::vector<int> zeros((size_t)(N_Q - 1) * sumT, 0);
   const long o_samples = mb.add(zeros);
   if (int e = upload_meta(c)) return e;
@@ -569,10 +609,13 @@ int nar_generate_once(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::v
     launch_add_pe_scatter(c->fx, mb.dev(o_yd), c->fyemb, W(c, "nar_audio_position.alpha"), c->pe, mb.dev(o_yp), (int)Y,
                           c->stream);
     const float* ada = c->ada + (size_t)st * nnorm * 2 * D_MODEL;
+    // the last layer only has to produce the generated rows (struct Trim); the per-layer taps want every row
+    const bool trim = c->nar_trim && c->gemm_mode == 0 && c->attn_x3 && c->attn_h2 && !c->cfg.debug_taps;
+    const Trim tr{sumT, mb.dev(o_qf), mb.dev(o_co), mb.dev(o_gr), trim_attn_flops};
     for (int l = 0; l < NL; ++l) {
       if (int e = full_layer(c, c->nar[l], M, mb.dev(o_off), mb.dev(o_len), nullptr, nb, max_len,
                              ada + (size_t)(2 * l) * 2 * D_MODEL, ada + (size_t)(2 * l + 1) * 2 * D_MODEL, nullptr, nullptr,
-                             nullptr, nullptr, attn_flops))
+                             nullptr, nullptr, attn_flops, (trim && l == NL - 1) ? &tr : nullptr))
         return e;
       if (c->cfg.debug_taps && st == 0) {
         char nm[64];
@@ -581,12 +624,22 @@ int nar_generate_once(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::v
       }
     }
     const float* adaf = ada + (size_t)(2 * NL) * 2 * D_MODEL;
-    launch_layernorm(c->fx, D_MODEL, c->fxn, D_MODEL, (int)M, D_MODEL, LN_EPS, W(c, "nar_decoder.norm.norm.weight"),
-                     W(c, "nar_decoder.norm.norm.bias"), adaf, adaf + D_MODEL, c->stream);
     char nm[64];
     snprintf(nm, sizeof nm, "nar_predict_layers.%d.weight", st);
-    proj(c, c->fxn, D_MODEL, W(c, nm), c->pred_w3[st], nullptr, nullptr, 0, c->flogits, AUDIO_VOCAB, sumT, AUDIO_VOCAB, D_MODEL,
-         ACT_NONE, mb.dev(o_gr));
+    if (trim) {
+      // the compacted residual stream (fxn) holds exactly the rows the predict layer reads: the final norm writes the GEMM's
+      // operand planes itself (bit-identical to a split of its fp32 result), no gather, no split pass
+      launch_layernorm(c->fxn, D_MODEL, nullptr, D_MODEL, (int)sumT, D_MODEL, LN_EPS, W(c, "nar_decoder.norm.norm.weight"),
+                       W(c, "nar_decoder.norm.norm.bias"), adaf, adaf + D_MODEL, c->stream, c->fa3, h2_plane(sumT, D_MODEL, H2_TILE_A),
+                       c->range_flag);
+      proj(c, nullptr, D_MODEL, W(c, nm), c->pred_w3[st], nullptr, nullptr, 0, c->flogits, AUDIO_VOCAB, sumT, AUDIO_VOCAB, D_MODEL,
+           ACT_NONE, nullptr, c->fa3);
+    } else {
+      launch_layernorm(c->fx, D_MODEL, c->fxn, D_MODEL, (int)M, D_MODEL, LN_EPS, W(c, "nar_decoder.norm.norm.weight"),
+                       W(c, "nar_decoder.norm.norm.bias"), adaf, adaf + D_MODEL, c->stream);
+      proj(c, c->fxn, D_MODEL, W(c, nm), c->pred_w3[st], nullptr, nullptr, 0, c->flogits, AUDIO_VOCAB, sumT, AUDIO_VOCAB, D_MODEL,
+           ACT_NONE, mb.dev(o_gr));
+    }
     if (c->cfg.debug_taps) {                             // "nar_logits0" .. "nar_logits6": every stage's logits of the generated rows
       snprintf(nm, sizeof nm, "nar_logits%d", st);
       if (int e = tap_store(c, nm, c->flogits, (size_t)sumT * AUDIO_VOCAB)) return e;

@@ -21,6 +21,8 @@
 // stage are threaded between the MFMAs of this K tile (one behind every sixth MFMA) instead of back to back behind the rendezvous
 // with the matrix pipe idle: -2 .. -7 % on the four NAR shapes (profiles/r03_gemm_bench.log, columns h2-256x256 vs -dma-spread),
 // same sums.  The timing probes this kernel grew up with live in tools/dev_src/gemm_f16x2_probes.hip (tools-only build).
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "vx_common.h"
@@ -106,7 +108,13 @@ void launch_absmax(const float* x, long n, unsigned* out_bits, hipStream_t s) {
 // NST = LDS stages: 2, or 4 for the 128 x 128 tile when there is at most ONE workgroup per CU anyway (one utterance: the K loop of a
 // lone workgroup is a chain of LDS-DMA round trips, ~0.8 us per K tile against 0.2 us of MFMAs; with the requests three tiles ahead
 // -- counted s_waitcnt vmcnt(16 / 8 / 0) before the barrier -- the round trips overlap).
-template <int TN, int TM, int NST = 2>
+// PRIO: wave priority (guide T5).  0 none;  1 static: the second-dispatched half of the workgroup's waves (wid >= NWAVE / 2) runs at
+// priority 1 throughout -- with two waves per SIMD the younger wave otherwise loses every arbitration to the older one;  2
+// s_setprio(1) around the 24 MFMAs of every k16 step.  The product instantiates VX_GEMM_PRIO; tools builds all three.
+#ifndef VX_GEMM_PRIO
+#define VX_GEMM_PRIO 0
+#endif
+template <int TN, int TM, int NST = 2, int PRIO = 0>
 __global__ __launch_bounds__(TM * 2, (TM == 256 || NST == 4) ? 1 : 2) void gemm_f16x2_kernel(GemmX3Args g) {
   constexpr int NWAVE = TM / 32;                                                 // 8 / 4 waves: TM / 64 along M x 2 along N
   constexpr int HA_PL = TM * HLD;                                                // 16 / 8 KiB per A plane and stage
@@ -138,6 +146,9 @@ __global__ __launch_bounds__(TM * 2, (TM == 256 || NST == 4) ? 1 : 2) void gemm_
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1, hi = lane >> 5, l31 = lane & 31;
+  if constexpr (PRIO == 1) {
+    if (wid >= NWAVE / 2) __builtin_amdgcn_s_setprio(1);         // wid is scalar (readfirstlane): s_setprio ignores EXEC
+  }
 
   // DMA plan: instruction q = wid * HNDMA + j of a stage; q < 32: A plane q / 16, rows 16 (q % 16) ..; else W plane
   // (q - 32) / (TN / 16), rows 16 ((q - 32) % (TN / 16)) ...  Lane -> (row l / 4 of the 16, LDS chunk slot l % 4), swizzle on the
@@ -208,6 +219,7 @@ __global__ __launch_bounds__(TM * 2, (TM == 256 || NST == 4) ? 1 : 2) void gemm_
   // on the same accumulator.  SPREAD (256-wide tile): DMA instruction 4 s + 0..3 of the next stage behind MFMAs 3, 9, 15, 21.
   auto kstep16 = [&](const f16x8 (&w)[2][NJ], const f16x8 (&a)[2][2], unsigned char* other, int kt_next, bool more, int s) {
     int n = 0;
+    if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
       const int wp = p == 0 ? 1 : 0, ap = p == 1 ? 1 : 0;
@@ -224,6 +236,7 @@ __global__ __launch_bounds__(TM * 2, (TM == 256 || NST == 4) ? 1 : 2) void gemm_
           }
         }
     }
+    if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);
   };
   f16x8 w0[2][NJ], a0[2][2], w1[2][TN == 128 ? NJ : 1], a1[2][2];
   auto ktile = [&](const unsigned char* stage, unsigned char* other, int kt_next, bool more) {
@@ -303,6 +316,7 @@ __global__ __launch_bounds__(TM * 2, (TM == 256 || NST == 4) ? 1 : 2) void gemm_
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + wm * 64 + i * 32 + l31;
     if (m >= g.M) continue;
+    const int mr = (g.resid && g.resid_rows) ? g.resid_rows[m] : m;      // residual row (compacted row sets read it through a map)
 #pragma unroll
     for (int jn = 0; jn < NJ; ++jn) {
       unsigned hw[4][2], tw[4][2];                               // [g4][pair]: packed fp16 heads / scaled tails (planes mode)
@@ -324,7 +338,7 @@ __global__ __launch_bounds__(TM * 2, (TM == 256 || NST == 4) ? 1 : 2) void gemm_
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (g.resid) {
-          const f32x4 rr = *reinterpret_cast<const f32x4*>(g.resid + (long)m * g.ldr + n);
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(g.resid + (long)mr * g.ldr + n);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = rr[e] + v[e];
         }
@@ -396,7 +410,14 @@ void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s, int tn) {
   if (two_stage) tm = 128;
   const int tiles = ((g.M + tm - 1) / tm) * ((g.N + tn - 1) / tn);
   if (tiles <= 0) return;
-  if (tn == 256) hipLaunchKernelGGL((gemm_f16x2_kernel<256, 256>), dim3(tiles), dim3(512), 0, s, g);
+#ifdef VX_DEV_PROBES
+  static const int env_prio = [] { const char* e = getenv("VX_GEMM_PRIO_RT"); return e ? atoi(e) : -1; }();
+  const int prio = g.dev_variant > 0 ? g.dev_variant : (env_prio >= 0 ? env_prio : VX_GEMM_PRIO);
+  if (tn == 256 && prio == 1) { hipLaunchKernelGGL((gemm_f16x2_kernel<256, 256, 2, 1>), dim3(tiles), dim3(512), 0, s, g); return; }
+  if (tn == 256 && prio == 2) { hipLaunchKernelGGL((gemm_f16x2_kernel<256, 256, 2, 2>), dim3(tiles), dim3(512), 0, s, g); return; }
+  if (tn == 256 && prio == 0) { hipLaunchKernelGGL((gemm_f16x2_kernel<256, 256, 2, 0>), dim3(tiles), dim3(512), 0, s, g); return; }
+#endif
+  if (tn == 256) hipLaunchKernelGGL((gemm_f16x2_kernel<256, 256, 2, VX_GEMM_PRIO>), dim3(tiles), dim3(512), 0, s, g);
   else if (tm == 128 && tiles <= 256 && !two_stage)      // at most one workgroup per CU: four LDS stages, requests three K tiles ahead
     hipLaunchKernelGGL((gemm_f16x2_kernel<128, 128, 4>), dim3(tiles), dim3(256), 0, s, g);
   else if (tm == 128) hipLaunchKernelGGL((gemm_f16x2_kernel<128, 128>), dim3(tiles), dim3(256), 0, s, g);

@@ -54,6 +54,8 @@ struct GemmX3Args {
   unsigned short* out_planes; long out_plane;   // plane stride in elements: h2_plane(M, N, H2_TILE_A)
   int* range_flag;
   float descale;                                // f16x2: 2^-(shift of A + shift of W), applied to the accumulator (exact)
+  const int* resid_rows;                        // f16x2 only, optional: row of `resid` for output row m (null = m): compacted row sets
+  int dev_variant;                              // tools builds only (-DVX_DEV_PROBES): > 0 selects a wave-priority variant of the 256 x 256 kernel
 };
 void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s, int tn = 0);     // 256 x (256 | 128) x 32 tiles, async LDS fill, any M
 // f16x2 planes are TILE-major: [rows / tile_rows][K/32][tile_rows][32], tile_rows = 256 (both operands);
@@ -129,7 +131,9 @@ void launch_attn_full_x3(const float* qkv, float* out, const int* seq_off, const
 // f16x2 version (attn_full_h2.hip): three f16 MFMAs per block, operands scaled by powers of two (see the file); *range_flag = 1
 // if an operand head did not fit fp16 (the output is then non-finite)
 void launch_attn_full_h2(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
-                         int batch, int max_len, hipStream_t s, unsigned short* planes, long plane_stride, int* range_flag);
+                         int batch, int max_len, hipStream_t s, unsigned short* planes, long plane_stride, int* range_flag,
+                         int prio = -1,       // prio >= 0: wave-priority variant (tools builds only; see the kernel)
+                         const int* q_first = nullptr, const int* c_off = nullptr);   // row trimming (planes mode; see the kernel)
 #ifdef VX_DEV_PROBES
 void launch_attn_full_probe(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
                             int batch, int max_len, int variant, hipStream_t s);   // timing probes (tools/attn_bench.py)
@@ -153,6 +157,10 @@ constexpr int SB_ROWS = 4;
 // instantiated and NOTHING was launched (the engine turns it into VX_EINVAL; a library must never abort() its host process).
 // sb_chain_supported: may the small-batch chain run with these split counts?  (otherwise the engine takes the general chain)
 bool sb_chain_supported(int sk_l2, int sk_out, int nsplit, int batch);
+// mid-size batches (2 .. 6 context splits): out_proj whose waves combine the context-split partials of THEIR head in the prologue
+bool hc_chain_supported(int sk_out, int nsplit);
+bool launch_skinny_gemm_hc(const float* Wp, float* partial_out, int splitk, const float* part_o, const float* part_ml, int nsplit,
+                           int batch, hipStream_t s);
 // partial_out[ks][b][n] = sum_k LN(resid[b] + sum_ks' partial_in[ks'][b] + bias)[k] W[n][k]   (K = 1024); workgroup 0 writes h_out
 bool launch_skinny_gemm_sb_ln(const float* Wp, float* partial_out, int Npad, int splitk, const float* partial_in, int sk_in,
                               const float* bias, const float* resid, float* h_out, const float* g, const float* b, int batch,

@@ -149,6 +149,8 @@ int vx_finalize_weights(vx_ctx* c) {
   if ((e = dev_alloc(c, &c->p_oh, (size_t)N_HEAD * MB * d))) return e;
   if (const char* ev = getenv("VX_FUSE_OUT")) c->fuse_out = !(ev[0] == '0');
   if (const char* ev = getenv("VX_BALANCE_ROWS")) c->balance_rows = !(ev[0] == '0');
+  if (const char* ev = getenv("VX_NAR_TRIM")) c->nar_trim = ev[0] == '1';
+  if (const char* ev = getenv("VX_MID_FUSE")) c->mid_fuse = ev[0] == '1';
   if ((e = dev_alloc(c, &c->p_logits, (size_t)SK_PRED * MB * PRED_NPAD))) return e;
   if ((e = dev_alloc(c, &c->part_o, (size_t)MB * N_HEAD * 16 * D_HEAD))) return e;
   if ((e = dev_alloc(c, &c->part_ml, (size_t)MB * N_HEAD * 16 * 2))) return e;
