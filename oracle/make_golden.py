@@ -261,7 +261,8 @@ def chain_second(c, codes1):
     return np.asarray(codes1, np.int64), own, np.concatenate([own, new], -1), pl, langs
 
 
-def run_reference(c, inputs=None, useed=None):
+def run_reference(c, inputs=None, useed=None, sd=None):
+    """`sd`: explicit weights instead of the case's synthetic recipe (tools/verify_checkpoint.py runs a real checkpoint through this)"""
     sys.path.insert(0, REF)
     sys.dont_write_bytecode = True
     import models.vallex as V
@@ -269,8 +270,8 @@ def run_reference(c, inputs=None, useed=None):
 
     m = VALLE(1024, 16, c["num_layers"], norm_first=True, add_prenet=False, prefix_mode=1,
               share_embedding=True, nar_scale_factor=1.0, prepend_bos=True, num_quantizers=8).eval()
-    sd = case_state_dict(c)
-    missing = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    sd = sd if sd is not None else case_state_dict(c)
+    missing = m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     a, t, text, pl, langs = inputs if inputs is not None else case_inputs(c)
     if useed is not None:

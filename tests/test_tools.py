@@ -60,3 +60,45 @@ def test_committed_resource_report_shows_no_spills():
     assert all(r["scratch"] == 0 for r in rows.values()), [n for n, r in rows.items() if r["scratch"]]
     assert rows["gemm_f16x2_kernel<256, 256, 2> (gemm_f16x2)"]["lds"] == 131072          # one 8-wave workgroup per CU
     assert rows["attn_full_h2_kernel (attn_full_h2)"]["occ"] == 2 and rows["dec_attn_kernel<true, 4> (decode)"]["occ"] == 4
+
+
+def _synthetic_checkpoint(tmp_path, layers=2):
+    import torch
+    from oracle import synth
+    sd = synth.vallex_state_dict(layers, 3, 1.0)
+    torch.save({"model": {k: torch.from_numpy(v) for k, v in sd.items()}, "epoch": 1}, tmp_path / "vallex-checkpoint.pt")
+    torch.save({k: torch.from_numpy(v) for k, v in synth.vocos_state_dict(2).items()}, tmp_path / "vocos.bin")
+    return str(tmp_path / "vallex-checkpoint.pt"), str(tmp_path / "vocos.bin")
+
+
+def _run_verifier(args):
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "verify_checkpoint.py")] + args, cwd=ROOT, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:] + r.stdout[-2000:]
+    return json.loads(r.stdout[r.stdout.index("{"):])
+
+
+def test_checkpoint_verifier_cpu_legs(tmp_path):
+    """tools/verify_checkpoint.py --no-gpu on a checkpoint FILE of the reference's layout: strict load through torch.load(...)
+    ["model"], operand headroom against the f16x2 limit -- what a user with the real vallex-checkpoint.pt runs first"""
+    ck, _ = _synthetic_checkpoint(tmp_path)
+    rep = _run_verifier(["--ckpt", ck, "--presets", os.path.join(ROOT, "tests", "golden", "presets"), "--max-presets", "1",
+                         "--n-text", "10", "--frames", "12", "--no-gpu"])
+    assert rep["ok"] and rep["load"]["strict"] and rep["load"]["keys"] == rep["load"]["expected_keys"] == 94
+    assert rep["load"]["num_layers"] == 2 and rep["load"]["checkpoint_top_level"] == ["epoch", "model"]
+    assert set(rep["headroom"]["max_abs_operand"]) == {"ln", "q8", "k", "v", "att", "ffn"} and rep["headroom"]["worst"] < 2047.0
+
+
+@pytest.mark.gpu
+def test_checkpoint_verifier_on_the_gpu(tmp_path):
+    """the GPU legs: ids of every preset job equal between the f16x2 and the fp32 arithmetic, no fallback, Vocos head within 1e-4
+    RMS of the CPU restatement -- the report a user gets from the real files"""
+    ck, vo = _synthetic_checkpoint(tmp_path)
+    rep = _run_verifier(["--ckpt", ck, "--vocos", vo, "--presets", os.path.join(ROOT, "tests", "golden", "presets"), "--max-presets",
+                         "2", "--n-text", "12", "--frames", "24"])
+    assert rep["ok"]
+    assert all(v["equal"] for v in rep["parity"]["cross_arith"].values()) and len(rep["parity"]["cross_arith"]) == 4
+    assert all(j["fallbacks"]["lifetime"] == 0 for j in rep["parity"]["f16x2"].values())
+    assert rep["vocos"]["rms_vs_cpu_restatement"] <= 1e-4 and "pip_vocos" in rep["vocos"]
