@@ -519,6 +519,11 @@ __global__ __launch_bounds__(256) void skinny_gemm_sb_kernel(const float* __rest
 bool sb_chain_supported(int sk_l2, int sk_out, int nsplit, int batch) {
   return (sk_l2 == 8 || sk_l2 == 4) && sk_out == 4 && (nsplit == 16 || nsplit == 8) && batch <= SB_MAX;
 }
+// ... with norm1 + QKV folded into the attention launch (dec_attn_qkv_kernel): nsplit context splits + 1 partial for the new token
+bool sb_qkv_chain_supported(int sk_l2, int sk_out, int nsplit, int batch) {
+  return sk_l2 == 8 && sk_out == 4 && (nsplit == 16 || nsplit == 14 || nsplit == 8 || nsplit == 6 || nsplit == 3 || nsplit == 2) &&
+         batch <= SB_MAX;
+}
 
 bool launch_skinny_gemm_sb_ln(const float* Wp, float* partial_out, int Npad, int splitk, const float* partial_in, int sk_in,
                               const float* bias, const float* resid, float* h_out, const float* g, const float* b, int batch,
@@ -543,6 +548,15 @@ bool launch_skinny_gemm_sb_combine(const float* Wp, float* partial_out, int Npad
   else if (nsplit == 8 && batch <= SB_MAX)
     hipLaunchKernelGGL((skinny_gemm_sb_kernel<1, 8>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, nullptr, 0,
                        nullptr, nullptr, nullptr, nullptr, nullptr, part_o, part_ml, nsplit, batch);
+  else if (nsplit == 17 && batch <= SB_MAX)      // 16 context splits + the new token's partial (dec_attn_qkv_kernel)
+    hipLaunchKernelGGL((skinny_gemm_sb_kernel<1, 17>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, nullptr, 0,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, part_o, part_ml, nsplit, batch);
+#define VX_SBC(NSV)                                                                                                              \
+  else if (nsplit == NSV && batch <= SB_MAX)                                                                                     \
+    hipLaunchKernelGGL((skinny_gemm_sb_kernel<1, NSV>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, nullptr, 0, \
+                       nullptr, nullptr, nullptr, nullptr, nullptr, part_o, part_ml, nsplit, batch);
+  VX_SBC(9) VX_SBC(15) VX_SBC(7) VX_SBC(4) VX_SBC(3)
+#undef VX_SBC
   else return false;                       // this many context splits x rows are not compiled in
   return true;
 }
@@ -908,6 +922,261 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
     }
   }
   VX_STAMP(6, 4);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Small batches, one launch fewer per layer (round 4): norm1 + the QKV projection + the context-split attention in ONE kernel.
+// At <= 2 rows the step is a chain of launch latencies (QKV GEMM 7.6 us, dec_attn 5.6 us per layer at batch 1,
+// profiles/r03_b1_kernel_stats.csv); every split workgroup of dec_attn already rebuilt q from the QKV slabs.  Here workgroup
+// (head h, slot y, z) computes what IT needs of in_proj (modules/activation.py:144) itself, on the VALU, from the raw fp32 weight
+// rows (a head's q / k / v slice is 64 rows x 4 KB, L2-resident after the first workgroup of the head touched it):
+//   z < nsplit      : q = W_q[h] x + b (64 x 1024), then the split's share of the cached keys / values as in dec_attn_kernel;
+//   z == nsplit     : q and k_new; appends k_new to the cache; the new token's own score d = q . k_new as the partial (m = d, l = 1);
+//   z == nsplit + 1 : v_new; appends it; it is the (unnormalised) output of that extra partial.
+// The combine (prologue of the out_proj GEMM) therefore sees nsplit + 1 partials.  x = norm1(h) comes from the prologue that the
+// QKV GEMM of the small-batch chain used to run: LayerNorm of (resid + sum of the SKP linear2 slabs + bias) for THIS row (one
+// 256-thread team, the body of dec_reduce_ln_pack), or -- layer 0, SKP = 0 -- the packed image the sampler left.  The weight
+// loads of the wave's first rows are requested before that prologue.  A wave owns 8 of the head's 64 output rows; a row is 4 float4
+// loads per lane (k = 4 lane + 256 i), 16 FMAs in a fixed order, one DPP wave sum.
+// ------------------------------------------------------------------------------------------------------------
+template <int SKP>
+__global__ __launch_bounds__(ATT_WAVES * 64, 2) void dec_attn_qkv_kernel(
+    const float* __restrict__ in_w, const float* __restrict__ in_b, float* __restrict__ kc, float* __restrict__ vc, int Tmax,
+    const int* __restrict__ slot_meta, float* __restrict__ part_o, float* __restrict__ part_ml, int nsplit,
+    const float* __restrict__ partial_in, const float* __restrict__ pbias, const float* __restrict__ resid,
+    float* __restrict__ h_out, const float* __restrict__ g, const float* __restrict__ bb, const float* __restrict__ xp) {
+  __shared__ __attribute__((aligned(16))) float xs[D_MODEL];
+  __shared__ __attribute__((aligned(16))) float sh_q[2][D_HEAD];          // [0] q (scaled), [1] k_new or v_new
+  __shared__ __attribute__((aligned(16))) float sh_o[ATT_WAVES][64];
+  __shared__ float sh_m[ATT_WAVES], sh_l[ATT_WAVES];
+  __shared__ float st[2][4];
+  const int slot = blockIdx.y;
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const i32x4 meta = *reinterpret_cast<const i32x4*>(slot_meta + 4 * slot);
+  const int h = blockIdx.x, b = meta[0], z = blockIdx.z;
+  if (meta[2] == 0) return;                                   // row finished: uniform over the workgroup
+  const int NS1 = nsplit + 1;                                 // partials per (row, head): nsplit context splits + the new token
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, gq = lane >> 4, c = lane & 15;
+  const int ctx = meta[1], npast = ctx - 1;
+  const long head_base = ((long)(b * N_HEAD + h) * Tmax) * D_HEAD;
+  const bool stream = z < nsplit;
+  // which 64-row slices of in_proj this workgroup contracts: [0] -> sh_q[0], [1] -> sh_q[1]
+  const int n_first = z == nsplit + 1 ? 2 * D_MODEL + h * D_HEAD : h * D_HEAD;          // V rows : Q rows
+  const bool two = z == nsplit;                                                        // Q and K rows
+  const f32x4* wrow = reinterpret_cast<const f32x4*>(in_w) + ((long)(n_first + wid * 8) * D_MODEL) / 4 + lane;
+  f32x4 wv[8][4];
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wv[r][i] = wrow[(long)r * (D_MODEL / 4) + 64 * i];
+
+  // this split's slice of the cached rows; first K/V tile in flight before the prologue (it does not depend on q)
+  const f32x4* kp = reinterpret_cast<const f32x4*>(kc + head_base) + c;
+  const f32x4* vp = reinterpret_cast<const f32x4*>(vc + head_base) + c;
+  const int chunk = ((npast + nsplit - 1) / nsplit + 15) & ~15;
+  const int t0 = stream ? z * chunk : 0;
+  const int t1 = stream ? ((t0 + chunk < npast) ? t0 + chunk : npast) : 0;
+  constexpr int RS = ATT_WAVES * 4;
+  int base = t0 + wid * 4 + gq;
+  f32x4 kA[ATT_U], vA[ATT_U], kB[ATT_U], vB[ATT_U];
+#define ATT_LOAD(KK, VV, BASE)                                             \
+  _Pragma("unroll") for (int u = 0; u < ATT_U; ++u) {                       \
+    int t = (BASE) + RS * u;                                               \
+    t = t < t1 ? t : t1 - 1;                                               \
+    KK[u] = __builtin_nontemporal_load(kp + (long)t * 16);                 \
+  }                                                                        \
+  _Pragma("unroll") for (int u = 0; u < ATT_U; ++u) {                       \
+    int t = (BASE) + RS * u;                                               \
+    t = t < t1 ? t : t1 - 1;                                               \
+    VV[u] = __builtin_nontemporal_load(vp + (long)t * 16);                 \
+  }
+  if (base < t1) { ATT_LOAD(kA, vA, base) }
+
+  // ---- x = norm1(h) of row b into LDS ----
+  if (SKP > 0) {
+    const int tt = threadIdx.x;
+    const bool team = tt < 256;                               // one 256-thread team (thread tt owns float4 column tt)
+    f32x4 v = {0.f, 0.f, 0.f, 0.f}, gg = v, be = v;
+    if (team) {
+      const int cc = tt * 4;
+      f32x4 p[SKP > 0 ? SKP : 1];
+#pragma unroll
+      for (int ks = 0; ks < SKP; ++ks) p[ks] = *reinterpret_cast<const f32x4*>(partial_in + ((long)ks * MB + b) * D_MODEL + cc);
+      gg = *reinterpret_cast<const f32x4*>(g + cc);
+      be = *reinterpret_cast<const f32x4*>(bb + cc);
+      const f32x4 rr = *reinterpret_cast<const f32x4*>(resid + (long)b * D_MODEL + cc);
+      const f32x4 bi = *reinterpret_cast<const f32x4*>(pbias + cc);
+      v = p[0];
+#pragma unroll
+      for (int ks = 1; ks < SKP; ++ks)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += p[ks][e];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += bi[e];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = rr[e] + v[e];
+      if (h_out && h == 0 && z == 0) *reinterpret_cast<f32x4*>(h_out + (long)b * D_MODEL + cc) = v;
+    }
+    const float s1 = wave_sum64((v[0] + v[1]) + (v[2] + v[3]));
+    if (team && (tt & 63) == 0) st[0][tt >> 6] = s1;
+    __syncthreads();
+    const float mean = ((st[0][0] + st[0][1]) + (st[0][2] + st[0][3])) * (1.0f / D_MODEL);
+    float q2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q2 += d * d; }
+    q2 = wave_sum64(q2);
+    if (team && (tt & 63) == 0) st[1][tt >> 6] = q2;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf(((st[1][0] + st[1][1]) + (st[1][2] + st[1][3])) * (1.0f / D_MODEL) + LN_EPS);
+    if (team) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * gg[e] + be[e];
+      *reinterpret_cast<f32x4*>(&xs[tt * 4]) = o;
+    }
+  } else if (threadIdx.x < 256) {
+    // layer 0: the sampler (or dec_embed_ln_pack) left norm1(h) in the packed image: float4 column c4 -> (c4 >> 1) * 64 + b + 32 (c4 & 1)
+    const int c4 = threadIdx.x;
+    *reinterpret_cast<f32x4*>(&xs[c4 * 4]) = *(reinterpret_cast<const f32x4*>(xp) + ((long)(c4 >> 1) * 64 + b + 32 * (c4 & 1)));
+  }
+  __syncthreads();
+
+  // ---- the wave's 8 rows of the first slice (and, workgroup z == nsplit, of the K slice) ----
+  f32x4 xv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const f32x4*>(&xs[(lane + 64 * i) * 4]);
+  auto rows8 = [&](int which, int n0) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = fmaf(wv[r][i][e], xv[i][e], acc);
+      acc = wave_sum64(acc);
+      if (lane == 0) sh_q[which][wid * 8 + r] = acc + in_b[n0 + wid * 8 + r];
+    }
+  };
+  rows8(0, n_first);
+  if (two) {
+    const f32x4* wk = reinterpret_cast<const f32x4*>(in_w) + ((long)(D_MODEL + h * D_HEAD + wid * 8) * D_MODEL) / 4 + lane;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wv[r][i] = wk[(long)r * (D_MODEL / 4) + 64 * i];
+    rows8(1, D_MODEL + h * D_HEAD);
+  }
+  __syncthreads();
+  const long pi = (long)(b * N_HEAD + h) * NS1 + (stream ? z : nsplit);
+  if (!stream) {
+    if (threadIdx.x < 16) {
+      const int cc = threadIdx.x;
+      if (two) {                                               // k_new: cache append + the new token's own partial (m = d, l = 1)
+        f32x4 q4 = *reinterpret_cast<const f32x4*>(&sh_q[0][cc * 4]);
+        const f32x4 k4 = *reinterpret_cast<const f32x4*>(&sh_q[1][cc * 4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q4[e] *= 0.125f;
+        *reinterpret_cast<f32x4*>(kc + head_base + (long)npast * D_HEAD + cc * 4) = k4;
+        float d = q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3];
+        d = dpp_sum16(d);
+        if (cc == 0) { part_ml[pi * 2] = d; part_ml[pi * 2 + 1] = 1.0f; }
+      } else {                                                 // v_new: cache append + the output of that partial (p = 1)
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(&sh_q[0][cc * 4]);
+        *reinterpret_cast<f32x4*>(vc + head_base + (long)npast * D_HEAD + cc * 4) = v4;
+        *reinterpret_cast<f32x4*>(part_o + pi * D_HEAD + cc * 4) = v4;
+      }
+    }
+    return;
+  }
+  f32x4 q4 = *reinterpret_cast<const f32x4*>(&sh_q[0][c * 4]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) q4[e] *= 0.125f;
+
+  float m = NEG_BIG, l = 0.f;
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#define ATT_CONSUME(KK, VV, BASE)                                                                  \
+  {                                                                                                \
+    float sc[ATT_U];                                                                               \
+    float m_new = m;                                                                               \
+    _Pragma("unroll") for (int u = 0; u < ATT_U; ++u) {                                             \
+      float d = q4[0] * KK[u][0] + q4[1] * KK[u][1] + q4[2] * KK[u][2] + q4[3] * KK[u][3];         \
+      d = dpp_sum16(d);                                                                            \
+      sc[u] = ((BASE) + RS * u < t1) ? d : NEG_BIG;                                                \
+      m_new = fmaxf(m_new, sc[u]);                                                                 \
+    }                                                                                              \
+    const float alpha = expf(m - m_new);                                                           \
+    l *= alpha;                                                                                    \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) o[e] *= alpha;                                    \
+    _Pragma("unroll") for (int u = 0; u < ATT_U; ++u) {                                             \
+      const float p = ((BASE) + RS * u < t1) ? expf(sc[u] - m_new) : 0.f;                          \
+      l += p;                                                                                      \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) o[e] += p * VV[u][e];                           \
+    }                                                                                              \
+    m = m_new;                                                                                     \
+  }
+  while (base < t1) {
+    int nb = base + ATT_STRIDE;
+    if (nb < t1) { ATT_LOAD(kB, vB, nb) }
+    ATT_CONSUME(kA, vA, base)
+    base = nb;
+    if (base >= t1) break;
+    nb = base + ATT_STRIDE;
+    if (nb < t1) { ATT_LOAD(kA, vA, nb) }
+    ATT_CONSUME(kB, vB, base)
+    base = nb;
+  }
+#undef ATT_LOAD
+#undef ATT_CONSUME
+  // combine the 4 lane-groups of the wave, then the waves through LDS (as dec_attn_kernel)
+#pragma unroll
+  for (int off = 16; off <= 32; off <<= 1) {
+    const float m2 = __shfl_xor(m, off, 64), l2 = __shfl_xor(l, off, 64);
+    f32x4 o2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o2[e] = __shfl_xor(o[e], off, 64);
+    const float mn = fmaxf(m, m2), a1 = expf(m - mn), a2 = expf(m2 - mn);
+    l = l * a1 + l2 * a2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = o[e] * a1 + o2[e] * a2;
+    m = mn;
+  }
+  if (gq == 0) {
+    *reinterpret_cast<f32x4*>(&sh_o[wid][c * 4]) = o;
+    if (c == 0) { sh_m[wid] = m; sh_l[wid] = l; }
+  }
+  __syncthreads();
+  if (wid == 0 && gq == 0) {
+    float mt = NEG_BIG;
+#pragma unroll
+    for (int w = 0; w < ATT_WAVES; ++w) mt = fmaxf(mt, sh_m[w]);
+    float lt = 0.f;
+    f32x4 ot = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < ATT_WAVES; ++w) {
+      const float a = expf(sh_m[w] - mt);
+      lt += sh_l[w] * a;
+      const f32x4 ow = *reinterpret_cast<const f32x4*>(&sh_o[w][c * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ot[e] += ow[e] * a;
+    }
+    *reinterpret_cast<f32x4*>(part_o + pi * D_HEAD + c * 4) = ot;
+    if (c == 0) { part_ml[pi * 2] = mt; part_ml[pi * 2 + 1] = lt; }
+  }
+}
+
+// false = configuration not instantiated (skp: slabs of the previous layer's linear2, 0 for layer 0)
+bool launch_dec_attn_qkv(const float* in_w, const float* in_b, float* kc, float* vc, int Tmax, const int* slot_meta, float* part_o,
+                         float* part_ml, int nsplit, int batch, const float* partial_in, int skp, const float* pbias,
+                         const float* resid, float* h_out, const float* g, const float* b, const float* xp, hipStream_t s) {
+  const dim3 grid(N_HEAD, batch, nsplit + 2), block(ATT_WAVES * 64);
+  if (skp == 8)
+    hipLaunchKernelGGL((dec_attn_qkv_kernel<8>), grid, block, 0, s, in_w, in_b, kc, vc, Tmax, slot_meta, part_o, part_ml, nsplit,
+                       partial_in, pbias, resid, h_out, g, b, xp);
+  else if (skp == 0)
+    hipLaunchKernelGGL((dec_attn_qkv_kernel<0>), grid, block, 0, s, in_w, in_b, kc, vc, Tmax, slot_meta, part_o, part_ml, nsplit,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, xp);
+  else return false;
+  return true;
 }
 
 bool launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias, float* kc, float* vc, int Tmax,

@@ -53,7 +53,8 @@ void gemm(vx_ctx* c, const float* A, int lda, const float* Wt, int ldw, const fl
 // GEMM's A planes (K = N) instead of fp32 rows (C may then be null).
 void proj(vx_ctx* c, const float* A, int lda, const float* Wf, const unsigned short* W3, const float* bias,
           const float* resid, int ldr, float* C, int ldc, long M, int N, int K, int act, const int* gather = nullptr,
-          const unsigned short* a_pre = nullptr, unsigned short* out_pl = nullptr, const int* resid_rows = nullptr) {
+          const unsigned short* a_pre = nullptr, unsigned short* out_pl = nullptr, const int* resid_rows = nullptr,
+          unsigned short* kv_planes = nullptr, long kv_stride = 0) {
   if (c->gemm_mode == 2 || !W3) {
     gemm(c, A, lda, Wf, K, bias, resid, ldr, nullptr, C, ldc, M, N, K, act, gather, 2);
     return;
@@ -69,6 +70,7 @@ void proj(vx_ctx* c, const float* A, int lda, const float* Wf, const unsigned sh
   g.colscale = nullptr; g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.act = act;
   g.out_planes = out_pl; g.out_plane = out_pl ? h2_plane(M, N, H2_TILE_A) : 0; g.range_flag = c->range_flag;
   g.resid_rows = resid_rows;                     // f16x2 kernel only (the one mode that trims rows)
+  g.kv_planes = kv_planes; g.kv_stride = kv_stride;
   if (c->gemm_mode == 0) g.descale = ldexpf(1.0f, -(H2_ACT_SHIFT + c->w_shift.at(W3)));
   ProfScope ps(c, 2);
   if (c->prof_on) c->prof[2].bytes += 2.0 * (double)M * N * K;
@@ -100,8 +102,11 @@ int full_layer(vx_ctx* c, const LayerW& L, long M, const int* seq_off, const int
   const long pl1024 = h2_plane(M, D_MODEL, H2_TILE_A);
   launch_layernorm(c->fx, D_MODEL, pl ? nullptr : c->fxn, D_MODEL, (int)M, D_MODEL, LN_EPS, L.n1_w, L.n1_b, ada1,
                    ada1 ? ada1 + D_MODEL : nullptr, c->stream, pl ? c->fa3 : nullptr, pl1024, c->range_flag);
+  // NAR layers (no KV cache to fill): the QKV GEMM hands K and V to the attention kernel already split into its fp16 operand planes
+  const bool kvp = c->kv_planes_on && c->fkv && !kcl && pl && c->attn_x3 && c->attn_h2;
+  const long kv_stride = (c->Mmax + 256) * (long)D_MODEL;
   proj(c, c->fxn, D_MODEL, L.in_w, L.in_w3, L.in_b, nullptr, 0, c->fqkv, 3 * D_MODEL, M, 3 * D_MODEL, D_MODEL, ACT_NONE, nullptr,
-       pl ? c->fa3 : nullptr);
+       pl ? c->fa3 : nullptr, nullptr, nullptr, kvp ? c->fkv : nullptr, kv_stride);
   if (kcl) launch_kv_scatter(c->fqkv, row_b, row_t, (int)M, kcl, vcl, c->Tmax, c->stream);
   const bool att_pl = pl && c->attn_x3;
   if (tr) {                                        // caller guarantees f16x2 projections + f16x2 attention
@@ -110,7 +115,7 @@ int full_layer(vx_ctx* c, const LayerW& L, long M, const int* seq_off, const int
       ProfScope ps(c, 3);
       if (c->prof_on) c->prof[3].bytes += tr->attn_flops;
       launch_attn_full_h2(c->fqkv, nullptr, seq_off, seq_len, prefix_len, batch, max_len, c->stream, c->fa3, plc, c->range_flag, -1,
-                          tr->q_first, tr->c_off);
+                          tr->q_first, tr->c_off, kvp ? c->fkv : nullptr, kv_stride);
     }
     // x' = x[kept rows] + out_proj(attention): residual read through the row map, result compacted in fxn
     proj(c, nullptr, D_MODEL, L.out_w, L.out_w3, L.out_b, c->fx, D_MODEL, c->fxn, D_MODEL, tr->Mc, D_MODEL, D_MODEL, ACT_NONE, nullptr,
@@ -126,7 +131,7 @@ int full_layer(vx_ctx* c, const LayerW& L, long M, const int* seq_off, const int
     if (c->prof_on) c->prof[3].bytes += attn_flops;
     if (c->attn_x3 && c->attn_h2)
       launch_attn_full_h2(c->fqkv, att_pl ? nullptr : c->fatt, seq_off, seq_len, prefix_len, batch, max_len, c->stream,
-                          att_pl ? c->fa3 : nullptr, pl1024, c->range_flag);
+                          att_pl ? c->fa3 : nullptr, pl1024, c->range_flag, -1, nullptr, nullptr, kvp ? c->fkv : nullptr, kv_stride);
     else if (c->attn_x3)
       launch_attn_full_x3(c->fqkv, att_pl ? nullptr : c->fatt, seq_off, seq_len, prefix_len, batch, max_len, 0, c->stream,
                           att_pl ? c->fa3 : nullptr, pl1024);
@@ -281,6 +286,15 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
   if (c->sb_fuse && nrows <= SB_ROWS) {
     const int ns = nrows <= 2 ? 16 : 8;
     if (sb_chain_supported(SK_L2, SK_OUT, ns, nrows)) { c->nsplit = ns; c->sb_chain = true; c->hc_chain = false; }
+    // ... with norm1 + QKV inside the attention launch for the smallest batches (VX_SB_QKV=<max rows>; its split count is tunable)
+    c->sb_qkv = false;
+    if (c->sb_chain && nrows <= c->sb_qkv_rows) {
+      // the fused kernel holds one 8-wave workgroup per CU (228 VGPRs): 16 heads x rows x (splits + 2) workgroups must fit 256 CUs
+      // in ONE round -- 14 / 6 / 3 / 2 context splits for 1 / 2 / 3 / 4 rows
+      const int fit[5] = {0, 14, 6, 3, 2};
+      const int ns2 = c->sb_qkv_nsplit > 0 ? c->sb_qkv_nsplit : fit[nrows];
+      if (sb_qkv_chain_supported(SK_L2, SK_OUT, ns2, nrows)) { c->nsplit = ns2; c->sb_qkv = true; }
+    }
   }
 
   launch_embed_rows(c->fx, mb.dev(o_dt), W(c, "ar_text_embedding.word_embeddings.weight"), mb.dev(o_it),
@@ -363,6 +377,18 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
     float *hr = c->dh, *hw = c->dh2;            // the sampler / embed kernel left h in dh
     for (int l = 0; l < NL; ++l) {
       const LayerW& L = c->ar[l];
+      if (c->sb_qkv) {
+        // 4 launches per layer: norm1 + QKV run inside the split attention launch (decode.hip: dec_attn_qkv_kernel), which hands
+        // nsplit + 1 partials per (row, head) to the out_proj prologue
+        {
+          ProfScope ps(c, 0);
+          LAUNCH(launch_dec_attn_qkv(L.in_w, L.in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax, c->slot_meta, c->part_o,
+                                     c->part_ml, c->nsplit, nb, l ? c->p_o : nullptr, l ? SK_L2 : 0, l ? c->ar[l - 1].l2_b : nullptr, hr,
+                                     hw, L.n1_w, L.n1_b, c->xp, st));
+          if (l) std::swap(hr, hw);
+        }
+        { ProfScope ps(c, 1); LAUNCH(launch_skinny_gemm_sb_combine(L.out_wp, c->p_o, D_MODEL, SK_OUT, c->part_o, c->part_ml, c->nsplit + 1, nb, st)); }
+      } else {
       {
         ProfScope ps(c, 1);
         if (l == 0) launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, st);      // xp = norm1(h) from the sampler
@@ -377,6 +403,7 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
                         c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, nullptr, c->p_oh, st));
       }
       { ProfScope ps(c, 1); LAUNCH(launch_skinny_gemm_sb_combine(L.out_wp, c->p_o, D_MODEL, SK_OUT, c->part_o, c->part_ml, c->nsplit, nb, st)); }
+      }
       {
         ProfScope ps(c, 1);
         LAUNCH(launch_skinny16_sb_ln(L.l1_wp, L.l1_b, c->xp4, D_FF, c->p_o, SK_OUT, L.out_b, hr, hw, L.n2_w, L.n2_b, nb, st));
@@ -518,7 +545,7 @@ int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int 
     }
   }
   char sig[160];
-  snprintf(sig, sizeof sig, "b%d ns%d c%d%d k%d t%a u%d f%d l%d", nb, c->nsplit, (int)c->sb_chain, (int)c->hc_chain, sa.top_k, sa.temperature,
+  snprintf(sig, sizeof sig, "b%d ns%d c%d%d%d k%d t%a u%d f%d l%d", nb, c->nsplit, (int)c->sb_chain, (int)c->hc_chain, (int)c->sb_qkv, sa.top_k, sa.temperature,
            sa.uniforms != nullptr, sa.force_eos_at, sa.sum_logp != nullptr);
   const int sync_every = s->sync_every > 0 ? s->sync_every : 8;
   // with a forced EOS every row is inactive after force_eos_at steps: do not run on to the next host poll
