@@ -1255,12 +1255,27 @@ __global__ __launch_bounds__(256) void skinny_gemm_hc_kernel(const float* __rest
   for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + (long)u * 64);
   const int b = lane & 31, hi = lane >> 5;
   const bool row = b < M;
-  {
+#pragma unroll
+  for (int u = 0; u < 8; ++u) x[u] = f32x4{0.f, 0.f, 0.f, 0.f};          // rows >= M are zero columns of the MFMA
+  if (row) {
+    // ALL 8 NS + NS loads of the lane are requested together (one memory round trip: the partials were written by other CUs a
+    // kernel ago); only the lanes of live rows issue them
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const long pi = (long)((row ? b : 0) * N_HEAD + head) * NS;
+    const long pi = (long)(b * N_HEAD + head) * NS;
     f32x2 ml[NS];
+    f32x4 po[8][NS];
 #pragma unroll
     for (int sp = 0; sp < NS; ++sp) ml[sp] = *reinterpret_cast<const f32x2*>(part_ml + (pi + sp) * 2);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) po[u][sp] = *reinterpret_cast<const f32x4*>(part_o + (pi + sp) * D_HEAD + (2 * u + hi) * 4);
+    // pin: every load above is requested before the first use below (the scheduler otherwise trades the single round trip for
+    // register pressure and walks the partials in batches)
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) asm volatile("" : "+v"(po[u][sp]));
     float mt = NEG_BIG;
 #pragma unroll
     for (int sp = 0; sp < NS; ++sp) mt = fmaxf(mt, ml[sp][0]);
@@ -1271,24 +1286,15 @@ __global__ __launch_bounds__(256) void skinny_gemm_hc_kernel(const float* __rest
       lt += ml[sp][1] * a[sp];
     }
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {                    // two rounds of 4 chunks: bounds the loads in flight to 4 NS
-      f32x4 po[4][NS];
+    for (int u = 0; u < 8; ++u) {
+      f32x4 ot = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int uu = 0; uu < 4; ++uu)
+      for (int sp = 0; sp < NS; ++sp)
 #pragma unroll
-        for (int sp = 0; sp < NS; ++sp)
-          po[uu][sp] = *reinterpret_cast<const f32x4*>(part_o + (pi + sp) * D_HEAD + (2 * (4 * half + uu) + hi) * 4);
+        for (int e = 0; e < 4; ++e) ot[e] += po[u][sp][e] * a[sp];
 #pragma unroll
-      for (int uu = 0; uu < 4; ++uu) {
-        f32x4 ot = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int sp = 0; sp < NS; ++sp)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) ot[e] += po[uu][sp][e] * a[sp];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ot[e] = row ? ot[e] / lt : 0.f;      // rows >= M are zero columns of the MFMA
-        x[4 * half + uu] = ot;
-      }
+      for (int e = 0; e < 4; ++e) ot[e] = ot[e] / lt;
+      x[u] = ot;
     }
   }
   f32x16 acc;
