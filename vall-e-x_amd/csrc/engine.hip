@@ -290,8 +290,10 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
     c->sb_qkv = false;
     if (c->sb_chain && nrows <= c->sb_qkv_rows) {
       // the fused kernel holds one 8-wave workgroup per CU (228 VGPRs): 16 heads x rows x (splits + 2) workgroups must fit 256 CUs
-      // in ONE round -- 14 / 6 / 3 / 2 context splits for 1 / 2 / 3 / 4 rows
-      const int fit[5] = {0, 14, 6, 3, 2};
+      // in ONE round -- at most 14 / 6 / 3 / 2 context splits for 1 / 2 / 3 / 4 rows
+      // (one row: 8 splits measured better than 14 -- 223 vs 226.5 ms of AR per utterance, profiles/r04_sb_qkv_ab.log: fewer
+      // workgroups re-read the head's weight slice through L2)
+      const int fit[5] = {0, 8, 6, 3, 2};
       const int ns2 = c->sb_qkv_nsplit > 0 ? c->sb_qkv_nsplit : fit[nrows];
       if (sb_qkv_chain_supported(SK_L2, SK_OUT, ns2, nrows)) { c->nsplit = ns2; c->sb_qkv = true; }
     }
@@ -463,24 +465,33 @@ int launch_status(vx_ctx* c) {
   FAIL(VX_EINVAL, "kernel configuration not compiled into this library: %s", what);
 }
 
-int ar_step_run(vx_ctx* c, const SampleArgs* sa, const std::string& sig) {
+// nsteps consecutive decode steps.  Graph mode keeps TWO instantiated graphs per signature: one step, and GRAPH_STEPS steps in one
+// graph -- between two hipGraphLaunch calls the GPU idles for ~9 us (kernel traces, profiles/r04_gaps_*.csv: the gap behind every
+// dec_sample launch), which a multi-step graph pays once per GRAPH_STEPS steps.  All step state (positions, lengths, flags, the
+// sampler's counters) lives on the device, so a replay is position independent.
+constexpr int GRAPH_STEPS = 4;
+int ar_step_run(vx_ctx* c, const SampleArgs* sa, const std::string& sig, int nsteps = 1) {
   if (!c->cfg.use_graph || c->prof_on == 1 || !sa) {
-    ar_step_launches(c, sa);
+    for (int i = 0; i < nsteps; ++i) ar_step_launches(c, sa);
     HIPCHK(hipGetLastError());
     return launch_status(c);
   }
-  if (!c->graph_exec || c->graph_sig != sig) {
-    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
-    hipGraph_t g = nullptr;
-    HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    ar_step_launches(c, sa);
-    HIPCHK(hipStreamEndCapture(c->stream, &g));
-    if (int e = launch_status(c)) { (void)hipGraphDestroy(g); return e; }      // an incomplete step must never be replayed
-    HIPCHK(hipGraphInstantiate(&c->graph_exec, g, nullptr, nullptr, 0));
-    (void)hipGraphDestroy(g);
+  if (c->graph_sig != sig) {
+    for (hipGraphExec_t* ge : {&c->graph_exec, &c->graph_exec_n})
+      if (*ge) { (void)hipGraphExecDestroy(*ge); *ge = nullptr; }
     c->graph_sig = sig;
   }
-  HIPCHK(hipGraphLaunch(c->graph_exec, c->stream));
+  hipGraphExec_t& ge = nsteps == 1 ? c->graph_exec : c->graph_exec_n;
+  if (!ge) {
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < nsteps; ++i) ar_step_launches(c, sa);
+    HIPCHK(hipStreamEndCapture(c->stream, &g));
+    if (int e = launch_status(c)) { (void)hipGraphDestroy(g); return e; }      // an incomplete step must never be replayed
+    HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+  }
+  HIPCHK(hipGraphLaunch(ge, c->stream));
   return VX_OK;
 }
 
@@ -551,9 +562,12 @@ int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int 
   // with a forced EOS every row is inactive after force_eos_at steps: do not run on to the next host poll
   const int hard_cap = s->force_eos_at >= 0 ? std::min(c->gen_stride + 2, s->force_eos_at) : c->gen_stride + 2;
   int steps = 0;
+  // GRAPH_STEPS steps per graph launch while that neither crosses a host poll nor the cap (nsteps is 1 or GRAPH_STEPS: two graphs)
+  const int gs = (c->graph_multi && sync_every % GRAPH_STEPS == 0) ? GRAPH_STEPS : 1;
   while (any && steps < hard_cap) {
-    if (int e = ar_step_run(c, &sa, sig)) return e;
-    ++steps;
+    const int n = (steps % gs == 0 && steps + gs <= hard_cap) ? gs : 1;
+    if (int e = ar_step_run(c, &sa, sig, n)) return e;
+    steps += n;
     if (steps % sync_every == 0) {
       HIPCHK(hipMemcpyAsync(act.data(), c->active, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
       HIPCHK(hipStreamSynchronize(c->stream));
@@ -777,6 +791,7 @@ void vx_destroy(vx_ctx* c) {
   (void)hipSetDevice(c->dev);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+  if (c->graph_exec_n) (void)hipGraphExecDestroy(c->graph_exec_n);
   for (auto& p : c->prof) for (auto ev : p.ev) (void)hipEventDestroy(ev);
   for (auto ev : c->ev_t) if (ev) (void)hipEventDestroy(ev);
   for (void* p : c->allocs) (void)hipFree(p);

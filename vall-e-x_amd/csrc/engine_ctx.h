@@ -103,7 +103,7 @@ struct vx_ctx {
   float *kc = nullptr, *vc = nullptr;      // [NL][mbr*16][Tmax][64]
   float *dh = nullptr, *dh2 = nullptr, *xp = nullptr, *xp_att = nullptr, *xp4 = nullptr;
   bool sb_qkv = false;             // ... on the small-batch chain with norm1 + QKV folded into the attention launch
-  int sb_qkv_rows = 0, sb_qkv_nsplit = 0;   // allow sb_qkv up to this many rows (VX_SB_QKV=n), forced split count (VX_SB_QKV_NSPLIT)
+  int sb_qkv_rows = 4, sb_qkv_nsplit = 0;   // sb_qkv up to this many rows (VX_SB_QKV=n, 0 = off), forced split count (VX_SB_QKV_NSPLIT)
   bool hc_chain = false;           // ... on the mid-size chain: out_proj combines the context splits per head in its prologue
   bool mid_fuse = false;           // allow hc_chain (VX_MID_FUSE=1)
   bool sb_chain = false;           // the current micro-batch decodes on the small-batch chain (set by ar_prefill)
@@ -125,7 +125,8 @@ struct vx_ctx {
   std::vector<int> h_L;            // prefill lengths of the current micro-batch
 
   // graph
-  hipGraphExec_t graph_exec = nullptr;
+  hipGraphExec_t graph_exec = nullptr, graph_exec_n = nullptr;   // one decode step / GRAPH_STEPS steps per launch
+  bool graph_multi = true;         // several steps per graph launch (VX_GRAPH_MULTI=0: one)
   std::string graph_sig;
 
   // taps
