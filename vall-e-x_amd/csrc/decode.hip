@@ -365,6 +365,19 @@ void launch_dec_reduce_ln_pack(const float* partial, int splitk, int npad, const
 // batch size it ran in.  The residual stream h ping-pongs between two buffers (workgroup 0 writes the new h while the others
 // still read the old one).  12 x 5 + 2 launches per step instead of 12 x 8 + 2.
 // ------------------------------------------------------------------------------------------------------------
+// sum over the 16 lanes of a DPP row (every lane of the row gets the total)
+__device__ __forceinline__ float dpp_sum16(float x) {
+  int v = __builtin_bit_cast(int, x);
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v = __builtin_bit_cast(int, x);
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v = __builtin_bit_cast(int, x);
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v = __builtin_bit_cast(int, x);
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));   // row_mirror
+  return x;
+}
+
 constexpr int SB_MAX = SB_ROWS;
 constexpr float NEG_BIG = -1e30f;
 
@@ -421,18 +434,30 @@ __device__ __forceinline__ void sb_reduce_ln_row(bool live, const float* __restr
 // float4 chunk tt & 15; splits in ascending order, ot / lt per element)
 // NS (the number of context splits) is a compile-time constant so that all 2 NS loads are requested together: a runtime loop
 // walked the splits one memory round trip at a time, twice (10.2 us per out_proj launch at batch 1, profiles/r03_b1_kernel_stats_v1.csv)
+// qk_new != null (the producer was dec_attn_qkv_kernel): the LAST partial is the new token's own -- (m = q . k_new, l = 1, o = v_new);
+// its m is formed here from qk_new[(row, head)][0] = q / 8 and [1] = k_new (the 16 threads of a head are one DPP row)
 template <int NS>
 __device__ __forceinline__ void sb_combine_row(const float* __restrict__ part_o, const float* __restrict__ part_ml, int m,
-                                               int tt, float* __restrict__ xs_row) {
+                                               int tt, float* __restrict__ xs_row, const float* __restrict__ qk_new) {
   const int h = tt >> 4, c = tt & 15;
   const long pi = (long)(m * N_HEAD + h) * NS;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   f32x2 ml[NS];
   f32x4 po[NS];
+  f32x4 qn = {0.f, 0.f, 0.f, 0.f}, kn = qn;
+  if (qk_new) {
+    qn = *reinterpret_cast<const f32x4*>(qk_new + ((long)(m * N_HEAD + h) * 2) * D_HEAD + c * 4);
+    kn = *reinterpret_cast<const f32x4*>(qk_new + ((long)(m * N_HEAD + h) * 2 + 1) * D_HEAD + c * 4);
+  }
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    ml[s] = *reinterpret_cast<const f32x2*>(part_ml + (pi + s) * 2);
+    if (!(qk_new && s == NS - 1)) ml[s] = *reinterpret_cast<const f32x2*>(part_ml + (pi + s) * 2);
     po[s] = *reinterpret_cast<const f32x4*>(part_o + (pi + s) * D_HEAD + c * 4);
+  }
+  {
+    float d = qn[0] * kn[0] + qn[1] * kn[1] + qn[2] * kn[2] + qn[3] * kn[3];
+    d = dpp_sum16(d);                                          // executed by every thread (full DPP rows)
+    if (qk_new) ml[NS - 1] = f32x2{d, 1.0f};
   }
   float mt = NEG_BIG;
 #pragma unroll
@@ -460,7 +485,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_sb_kernel(const float* __rest
                                                              const float* __restrict__ resid, float* __restrict__ h_out,
                                                              const float* __restrict__ g, const float* __restrict__ bb,
                                                              const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                                             int nsplit, int M) {
+                                                             int nsplit, int M, const float* __restrict__ qk_new) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   __shared__ __attribute__((aligned(16))) float xs[SB_MAX][D_MODEL];
   __shared__ float st[2][4];
@@ -477,7 +502,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_sb_kernel(const float* __rest
   const bool first = blockIdx.x == 0 && blockIdx.y == 0;
   for (int m = 0; m < M; ++m) {
     if (MODE == 0) sb_reduce_ln_row<SK>(true, partial, pnpad, bias, resid, first ? h_out : nullptr, g, bb, m, threadIdx.x, st, xs[m]);
-    else sb_combine_row<SK>(part_o, part_ml, m, threadIdx.x, xs[m]);
+    else sb_combine_row<SK>(part_o, part_ml, m, threadIdx.x, xs[m], qk_new);
   }
   __syncthreads();
   // x fragment of lane (b = lane & 31, hi = lane >> 5) for k-block kb: x[b][8 kb + 4 hi ..]; rows >= M are zero columns of the MFMA
@@ -521,8 +546,7 @@ bool sb_chain_supported(int sk_l2, int sk_out, int nsplit, int batch) {
 }
 // ... with norm1 + QKV folded into the attention launch (dec_attn_qkv_kernel): nsplit context splits + 1 partial for the new token
 bool sb_qkv_chain_supported(int sk_l2, int sk_out, int nsplit, int batch) {
-  return sk_l2 == 8 && sk_out == 4 && (nsplit == 16 || nsplit == 14 || nsplit == 8 || nsplit == 6 || nsplit == 3 || nsplit == 2) &&
-         batch <= SB_MAX;
+  return sk_l2 == 8 && sk_out == 4 && (nsplit == 16 || nsplit == 8 || nsplit == 4) && batch <= SB_MAX;
 }
 
 bool launch_skinny_gemm_sb_ln(const float* Wp, float* partial_out, int Npad, int splitk, const float* partial_in, int sk_in,
@@ -530,32 +554,26 @@ bool launch_skinny_gemm_sb_ln(const float* Wp, float* partial_out, int Npad, int
                               hipStream_t s) {
   if (sk_in == 8)
     hipLaunchKernelGGL((skinny_gemm_sb_kernel<0, 8>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, partial_in,
-                       D_MODEL, bias, resid, h_out, g, b, nullptr, nullptr, 0, batch);
+                       D_MODEL, bias, resid, h_out, g, b, nullptr, nullptr, 0, batch, nullptr);
   else if (sk_in == 4)
     hipLaunchKernelGGL((skinny_gemm_sb_kernel<0, 4>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, partial_in,
-                       D_MODEL, bias, resid, h_out, g, b, nullptr, nullptr, 0, batch);
+                       D_MODEL, bias, resid, h_out, g, b, nullptr, nullptr, 0, batch, nullptr);
   else return false;                       // split-K factor of the producer not compiled in
   return true;
 }
 
 bool launch_skinny_gemm_sb_combine(const float* Wp, float* partial_out, int Npad, int splitk, const float* part_o, const float* part_ml,
-                                   int nsplit, int batch, hipStream_t s) {
+                                   int nsplit, int batch, hipStream_t s, const float* qk_new) {
+  // nsplit = number of partials per (row, head).  qk_new != null: the last one is the new token's (dec_attn_qkv_kernel).
   // (tried for 5 .. 8 rows as well -- BASELINE config 5 decodes 8 -- with 4 splits: 134.7 vs 138.5 audio-s/s, the 8-row prologue
   // costs more than the combine launch it removes; DESIGN.md dead-end table)
-  if (nsplit == 16 && batch <= SB_MAX)
-    hipLaunchKernelGGL((skinny_gemm_sb_kernel<1, 16>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, nullptr, 0,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, part_o, part_ml, nsplit, batch);
-  else if (nsplit == 8 && batch <= SB_MAX)
-    hipLaunchKernelGGL((skinny_gemm_sb_kernel<1, 8>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, nullptr, 0,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, part_o, part_ml, nsplit, batch);
-  else if (nsplit == 17 && batch <= SB_MAX)      // 16 context splits + the new token's partial (dec_attn_qkv_kernel)
-    hipLaunchKernelGGL((skinny_gemm_sb_kernel<1, 17>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, nullptr, 0,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, part_o, part_ml, nsplit, batch);
+  if (batch > SB_MAX) return false;
 #define VX_SBC(NSV)                                                                                                              \
-  else if (nsplit == NSV && batch <= SB_MAX)                                                                                     \
+  else if (nsplit == NSV)                                                                                                        \
     hipLaunchKernelGGL((skinny_gemm_sb_kernel<1, NSV>), dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, partial_out, Npad, splitk, nullptr, 0, \
-                       nullptr, nullptr, nullptr, nullptr, nullptr, part_o, part_ml, nsplit, batch);
-  VX_SBC(9) VX_SBC(15) VX_SBC(7) VX_SBC(4) VX_SBC(3)
+                       nullptr, nullptr, nullptr, nullptr, nullptr, part_o, part_ml, nsplit, batch, qk_new);
+  if (false) {}
+  VX_SBC(16) VX_SBC(8) VX_SBC(17) VX_SBC(9) VX_SBC(5)
 #undef VX_SBC
   else return false;                       // this many context splits x rows are not compiled in
   return true;
@@ -666,17 +684,6 @@ void launch_dec_embed_ln_pack(const int* tok, const int* pos, const float* tab, 
 // dec_attn: softmax(q.K^T/8).V over the cache for one new token per row  (modules/activation.py:148-165 with T=1).
 // grid = (head, row, split).  Lane = (g = lane>>4 : row slot, c = lane&15 : float4 chunk of the 64-float row).
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float dpp_sum16(float x) {
-  int v = __builtin_bit_cast(int, x);
-  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-  v = __builtin_bit_cast(int, x);
-  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-  v = __builtin_bit_cast(int, x);
-  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));   // row_half_mirror
-  v = __builtin_bit_cast(int, x);
-  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));   // row_mirror
-  return x;
-}
 
 constexpr int ATT_U = 4;              // rows per lane-group per buffer; two buffers in flight (2 x 8 KiB per wave)
 constexpr int ATT_WAVES = 8;          // 512-thread workgroup
@@ -926,27 +933,34 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
 
 // ------------------------------------------------------------------------------------------------------------
 // Small batches, one launch fewer per layer (round 4): norm1 + the QKV projection + the context-split attention in ONE kernel.
-// At <= 2 rows the step is a chain of launch latencies (QKV GEMM 7.6 us, dec_attn 5.6 us per layer at batch 1,
-// profiles/r03_b1_kernel_stats.csv); every split workgroup of dec_attn already rebuilt q from the QKV slabs.  Here workgroup
-// (head h, slot y, z) computes what IT needs of in_proj (modules/activation.py:144) itself, on the VALU, from the raw fp32 weight
-// rows (a head's q / k / v slice is 64 rows x 4 KB, L2-resident after the first workgroup of the head touched it):
-//   z < nsplit      : q = W_q[h] x + b (64 x 1024), then the split's share of the cached keys / values as in dec_attn_kernel;
-//   z == nsplit     : q and k_new; appends k_new to the cache; the new token's own score d = q . k_new as the partial (m = d, l = 1);
-//   z == nsplit + 1 : v_new; appends it; it is the (unnormalised) output of that extra partial.
-// The combine (prologue of the out_proj GEMM) therefore sees nsplit + 1 partials.  x = norm1(h) comes from the prologue that the
-// QKV GEMM of the small-batch chain used to run: LayerNorm of (resid + sum of the SKP linear2 slabs + bias) for THIS row (one
-// 256-thread team, the body of dec_reduce_ln_pack), or -- layer 0, SKP = 0 -- the packed image the sampler left.  The weight
-// loads of the wave's first rows are requested before that prologue.  A wave owns 8 of the head's 64 output rows; a row is 4 float4
-// loads per lane (k = 4 lane + 256 i), 16 FMAs in a fixed order, one DPP wave sum.
+// At <= 4 rows the step is a chain of launch latencies (QKV GEMM 7.5 us + dec_attn 5.6 us per layer at batch 1,
+// profiles/r04_gaps_b1a.csv); every split workgroup of dec_attn already rebuilt q from the QKV slabs.  Here workgroup
+// (head h, slot y, split z) computes what IT needs of in_proj (modules/activation.py:144) itself, on the VALU, from the raw fp32
+// weight rows (a head's q slice is 64 rows x 4 KB, L2-resident after the first workgroup of the head touched it):
+//   * q = W_q[h] x + b (64 rows, 8 per wave; a row is 4 float4 loads per lane, k = 4 lane + 256 i, 16 FMAs in a fixed order, one DPP
+//     wave sum) -- all 32 loads of a lane are requested before the LayerNorm prologue;
+//   * its SHARE of the new token's key and value: rows [z R, (z + 1) R) of W_k[h] and of W_v[h], R = 64 / NSPL -- requested right
+//     behind the q rows' FMAs, so their L2 latency runs under the K/V stream, and finished after it: appended to the cache, k_new
+//     also into qk_new (with q, for the consumer), v_new as the output of the extra partial;
+//   * then the split's share of the cached keys / values exactly as dec_attn_kernel.
+// The new token's own partial is (m = q . k_new, l = 1, o = v_new): its m needs all 64 k_new values, which no single workgroup has --
+// the consumer (prologue of the out_proj GEMM, sb_combine_row) forms the dot product from qk_new.  So the combine sees NSPL + 1
+// partials.  x = norm1(h) comes from the prologue the QKV GEMM of the small-batch chain used to run: LayerNorm of (resid + sum of
+// the SKP linear2 slabs + bias) for THIS row (one 256-thread team, the body of dec_reduce_ln_pack), or -- layer 0, SKP = 0 -- the
+// packed image the sampler left.  (First version, measured in profiles/r04_sb_qkv_ab.log: two extra workgroups per (head, row) for
+// k_new / v_new; the one with q AND k_new to contract set the kernel's duration, 10.8 us at one row.)
 // ------------------------------------------------------------------------------------------------------------
-template <int SKP>
+template <int SKP, int NSPL>
 __global__ __launch_bounds__(ATT_WAVES * 64, 2) void dec_attn_qkv_kernel(
     const float* __restrict__ in_w, const float* __restrict__ in_b, float* __restrict__ kc, float* __restrict__ vc, int Tmax,
-    const int* __restrict__ slot_meta, float* __restrict__ part_o, float* __restrict__ part_ml, int nsplit,
+    const int* __restrict__ slot_meta, float* __restrict__ part_o, float* __restrict__ part_ml, float* __restrict__ qk_new,
     const float* __restrict__ partial_in, const float* __restrict__ pbias, const float* __restrict__ resid,
     float* __restrict__ h_out, const float* __restrict__ g, const float* __restrict__ bb, const float* __restrict__ xp) {
+  constexpr int R = D_HEAD / NSPL;                             // rows of k_new and of v_new this workgroup contracts
+  constexpr int E = 2 * R / ATT_WAVES;                         // ... per wave (NSPL 16 / 8 / 4 / 2 -> 1 / 2 / 4 / 8)
+  static_assert(R * NSPL == D_HEAD && E * ATT_WAVES == 2 * R && E >= 1, "NSPL must be 2, 4, 8 or 16");
   __shared__ __attribute__((aligned(16))) float xs[D_MODEL];
-  __shared__ __attribute__((aligned(16))) float sh_q[2][D_HEAD];          // [0] q (scaled), [1] k_new or v_new
+  __shared__ __attribute__((aligned(16))) float sh_q[D_HEAD];
   __shared__ __attribute__((aligned(16))) float sh_o[ATT_WAVES][64];
   __shared__ float sh_m[ATT_WAVES], sh_l[ATT_WAVES];
   __shared__ float st[2][4];
@@ -955,27 +969,23 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void dec_attn_qkv_kernel(
   const i32x4 meta = *reinterpret_cast<const i32x4*>(slot_meta + 4 * slot);
   const int h = blockIdx.x, b = meta[0], z = blockIdx.z;
   if (meta[2] == 0) return;                                   // row finished: uniform over the workgroup
-  const int NS1 = nsplit + 1;                                 // partials per (row, head): nsplit context splits + the new token
+  constexpr int NS1 = NSPL + 1;                               // partials per (row, head): the context splits + the new token
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, gq = lane >> 4, c = lane & 15;
   const int ctx = meta[1], npast = ctx - 1;
   const long head_base = ((long)(b * N_HEAD + h) * Tmax) * D_HEAD;
-  const bool stream = z < nsplit;
-  // which 64-row slices of in_proj this workgroup contracts: [0] -> sh_q[0], [1] -> sh_q[1]
-  const int n_first = z == nsplit + 1 ? 2 * D_MODEL + h * D_HEAD : h * D_HEAD;          // V rows : Q rows
-  const bool two = z == nsplit;                                                        // Q and K rows
-  const f32x4* wrow = reinterpret_cast<const f32x4*>(in_w) + ((long)(n_first + wid * 8) * D_MODEL) / 4 + lane;
+  const f32x4* w4 = reinterpret_cast<const f32x4*>(in_w) + lane;              // float4 column `lane` of row 0
   f32x4 wv[8][4];
 #pragma unroll
   for (int r = 0; r < 8; ++r)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wv[r][i] = wrow[(long)r * (D_MODEL / 4) + 64 * i];
+    for (int i = 0; i < 4; ++i) wv[r][i] = w4[(long)(h * D_HEAD + wid * 8 + r) * (D_MODEL / 4) + 64 * i];
 
   // this split's slice of the cached rows; first K/V tile in flight before the prologue (it does not depend on q)
   const f32x4* kp = reinterpret_cast<const f32x4*>(kc + head_base) + c;
   const f32x4* vp = reinterpret_cast<const f32x4*>(vc + head_base) + c;
-  const int chunk = ((npast + nsplit - 1) / nsplit + 15) & ~15;
-  const int t0 = stream ? z * chunk : 0;
-  const int t1 = stream ? ((t0 + chunk < npast) ? t0 + chunk : npast) : 0;
+  const int chunk = ((npast + NSPL - 1) / NSPL + 15) & ~15;
+  const int t0 = z * chunk;
+  const int t1 = (t0 + chunk < npast) ? t0 + chunk : npast;
   constexpr int RS = ATT_WAVES * 4;
   int base = t0 + wid * 4 + gq;
   f32x4 kA[ATT_U], vA[ATT_U], kB[ATT_U], vB[ATT_U];
@@ -1041,56 +1051,34 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void dec_attn_qkv_kernel(
   }
   __syncthreads();
 
-  // ---- the wave's 8 rows of the first slice (and, workgroup z == nsplit, of the K slice) ----
+  // ---- q: the wave's 8 rows ----
   f32x4 xv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const f32x4*>(&xs[(lane + 64 * i) * 4]);
-  auto rows8 = [&](int which, int n0) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      float acc = 0.f;
+  for (int r = 0; r < 8; ++r) {
+    float acc = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = fmaf(wv[r][i][e], xv[i][e], acc);
-      acc = wave_sum64(acc);
-      if (lane == 0) sh_q[which][wid * 8 + r] = acc + in_b[n0 + wid * 8 + r];
-    }
-  };
-  rows8(0, n_first);
-  if (two) {
-    const f32x4* wk = reinterpret_cast<const f32x4*>(in_w) + ((long)(D_MODEL + h * D_HEAD + wid * 8) * D_MODEL) / 4 + lane;
+      for (int e = 0; e < 4; ++e) acc = fmaf(wv[r][i][e], xv[i][e], acc);
+    acc = wave_sum64(acc);
+    if (lane == 0) sh_q[wid * 8 + r] = (acc + in_b[h * D_HEAD + wid * 8 + r]) * 0.125f;
+  }
+  // ---- this wave's E rows of the workgroup's k_new / v_new share: requested now, contracted behind the stream ----
+  // extra row e = wid E + r of the 2R: e < R is k_new[z R + e], else v_new[z R + e - R]
+  f32x4 we[E][4];
+  int erow[E];
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
+  for (int r = 0; r < E; ++r) {
+    const int e = wid * E + r;
+    erow[r] = (e < R ? D_MODEL + h * D_HEAD + z * R + e : 2 * D_MODEL + h * D_HEAD + z * R + (e - R));
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wv[r][i] = wk[(long)r * (D_MODEL / 4) + 64 * i];
-    rows8(1, D_MODEL + h * D_HEAD);
+    for (int i = 0; i < 4; ++i) we[r][i] = w4[(long)erow[r] * (D_MODEL / 4) + 64 * i];
   }
   __syncthreads();
-  const long pi = (long)(b * N_HEAD + h) * NS1 + (stream ? z : nsplit);
-  if (!stream) {
-    if (threadIdx.x < 16) {
-      const int cc = threadIdx.x;
-      if (two) {                                               // k_new: cache append + the new token's own partial (m = d, l = 1)
-        f32x4 q4 = *reinterpret_cast<const f32x4*>(&sh_q[0][cc * 4]);
-        const f32x4 k4 = *reinterpret_cast<const f32x4*>(&sh_q[1][cc * 4]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) q4[e] *= 0.125f;
-        *reinterpret_cast<f32x4*>(kc + head_base + (long)npast * D_HEAD + cc * 4) = k4;
-        float d = q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3];
-        d = dpp_sum16(d);
-        if (cc == 0) { part_ml[pi * 2] = d; part_ml[pi * 2 + 1] = 1.0f; }
-      } else {                                                 // v_new: cache append + the output of that partial (p = 1)
-        const f32x4 v4 = *reinterpret_cast<const f32x4*>(&sh_q[0][cc * 4]);
-        *reinterpret_cast<f32x4*>(vc + head_base + (long)npast * D_HEAD + cc * 4) = v4;
-        *reinterpret_cast<f32x4*>(part_o + pi * D_HEAD + cc * 4) = v4;
-      }
-    }
-    return;
-  }
-  f32x4 q4 = *reinterpret_cast<const f32x4*>(&sh_q[0][c * 4]);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) q4[e] *= 0.125f;
+  const f32x4 q4 = *reinterpret_cast<const f32x4*>(&sh_q[c * 4]);                   // already scaled by 1/8
+  if (z == 0 && threadIdx.x < 16) *reinterpret_cast<f32x4*>(qk_new + ((long)(b * N_HEAD + h) * 2) * D_HEAD + c * 4) = q4;
 
   float m = NEG_BIG, l = 0.f;
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
@@ -1127,6 +1115,30 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void dec_attn_qkv_kernel(
   }
 #undef ATT_LOAD
 #undef ATT_CONSUME
+  // ---- the share of k_new / v_new (weights long arrived) ----
+  const long pn = (long)(b * N_HEAD + h) * NS1 + NSPL;                                // the new token's partial
+#pragma unroll
+  for (int r = 0; r < E; ++r) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = fmaf(we[r][i][e], xv[i][e], acc);
+    acc = wave_sum64(acc);
+    if (lane == 0) {
+      const int e = wid * E + r;
+      const float val = acc + in_b[erow[r]];
+      if (e < R) {                                             // k_new[d], d = z R + e: cache append + for the consumer's q . k_new
+        const int d = z * R + e;
+        kc[head_base + (long)npast * D_HEAD + d] = val;
+        qk_new[((long)(b * N_HEAD + h) * 2 + 1) * D_HEAD + d] = val;
+      } else {                                                 // v_new[d]: cache append + the output of the new token's partial (p = 1)
+        const int d = z * R + (e - R);
+        vc[head_base + (long)npast * D_HEAD + d] = val;
+        part_o[pn * D_HEAD + d] = val;
+      }
+    }
+  }
   // combine the 4 lane-groups of the wave, then the waves through LDS (as dec_attn_kernel)
 #pragma unroll
   for (int off = 16; off <= 32; off <<= 1) {
@@ -1159,23 +1171,28 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void dec_attn_qkv_kernel(
 #pragma unroll
       for (int e = 0; e < 4; ++e) ot[e] += ow[e] * a;
     }
+    const long pi = (long)(b * N_HEAD + h) * NS1 + z;
     *reinterpret_cast<f32x4*>(part_o + pi * D_HEAD + c * 4) = ot;
     if (c == 0) { part_ml[pi * 2] = mt; part_ml[pi * 2 + 1] = lt; }
   }
 }
 
-// false = configuration not instantiated (skp: slabs of the previous layer's linear2, 0 for layer 0)
+// false = configuration not instantiated (skp: slabs of the previous layer's linear2, 0 for layer 0; nsplit 4 / 8 / 16)
 bool launch_dec_attn_qkv(const float* in_w, const float* in_b, float* kc, float* vc, int Tmax, const int* slot_meta, float* part_o,
-                         float* part_ml, int nsplit, int batch, const float* partial_in, int skp, const float* pbias,
+                         float* part_ml, float* qk_new, int nsplit, int batch, const float* partial_in, int skp, const float* pbias,
                          const float* resid, float* h_out, const float* g, const float* b, const float* xp, hipStream_t s) {
-  const dim3 grid(N_HEAD, batch, nsplit + 2), block(ATT_WAVES * 64);
-  if (skp == 8)
-    hipLaunchKernelGGL((dec_attn_qkv_kernel<8>), grid, block, 0, s, in_w, in_b, kc, vc, Tmax, slot_meta, part_o, part_ml, nsplit,
-                       partial_in, pbias, resid, h_out, g, b, xp);
-  else if (skp == 0)
-    hipLaunchKernelGGL((dec_attn_qkv_kernel<0>), grid, block, 0, s, in_w, in_b, kc, vc, Tmax, slot_meta, part_o, part_ml, nsplit,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, xp);
-  else return false;
+  const dim3 grid(N_HEAD, batch, nsplit), block(ATT_WAVES * 64);
+#define VX_AQ(SKPV, NSV)                                                                                                          \
+  hipLaunchKernelGGL((dec_attn_qkv_kernel<SKPV, NSV>), grid, block, 0, s, in_w, in_b, kc, vc, Tmax, slot_meta, part_o, part_ml, qk_new, \
+                     partial_in, pbias, resid, h_out, g, b, xp)
+  if (skp == 8) {
+    if (nsplit == 16) VX_AQ(8, 16); else if (nsplit == 8) VX_AQ(8, 8); else if (nsplit == 4) VX_AQ(8, 4);
+    else return false;                   // (2 splits = 8 extra weight rows per wave in flight: spills)
+  } else if (skp == 0) {
+    if (nsplit == 16) VX_AQ(0, 16); else if (nsplit == 8) VX_AQ(0, 8); else if (nsplit == 4) VX_AQ(0, 4);
+    else return false;
+  } else return false;
+#undef VX_AQ
   return true;
 }
 

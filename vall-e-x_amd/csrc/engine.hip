@@ -289,11 +289,9 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
     // ... with norm1 + QKV inside the attention launch for the smallest batches (VX_SB_QKV=<max rows>; its split count is tunable)
     c->sb_qkv = false;
     if (c->sb_chain && nrows <= c->sb_qkv_rows) {
-      // the fused kernel holds one 8-wave workgroup per CU (228 VGPRs): 16 heads x rows x (splits + 2) workgroups must fit 256 CUs
-      // in ONE round -- at most 14 / 6 / 3 / 2 context splits for 1 / 2 / 3 / 4 rows
-      // (one row: 8 splits measured better than 14 -- 223 vs 226.5 ms of AR per utterance, profiles/r04_sb_qkv_ab.log: fewer
-      // workgroups re-read the head's weight slice through L2)
-      const int fit[5] = {0, 8, 6, 3, 2};
+      // the fused kernel holds one 8-wave workgroup per CU: 16 heads x rows x splits workgroups must fit the 256 CUs in ONE round,
+      // and every workgroup of a head re-reads the head's q slice through L2 -- few splits win (profiles/r04_sb_qkv_ab.log)
+      const int fit[5] = {0, 8, 8, 4, 4};
       const int ns2 = c->sb_qkv_nsplit > 0 ? c->sb_qkv_nsplit : fit[nrows];
       if (sb_qkv_chain_supported(SK_L2, SK_OUT, ns2, nrows)) { c->nsplit = ns2; c->sb_qkv = true; }
     }
@@ -385,11 +383,14 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
         {
           ProfScope ps(c, 0);
           LAUNCH(launch_dec_attn_qkv(L.in_w, L.in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax, c->slot_meta, c->part_o,
-                                     c->part_ml, c->nsplit, nb, l ? c->p_o : nullptr, l ? SK_L2 : 0, l ? c->ar[l - 1].l2_b : nullptr, hr,
-                                     hw, L.n1_w, L.n1_b, c->xp, st));
+                                     c->part_ml, c->qk_new, c->nsplit, nb, l ? c->p_o : nullptr, l ? SK_L2 : 0,
+                                     l ? c->ar[l - 1].l2_b : nullptr, hr, hw, L.n1_w, L.n1_b, c->xp, st));
           if (l) std::swap(hr, hw);
         }
-        { ProfScope ps(c, 1); LAUNCH(launch_skinny_gemm_sb_combine(L.out_wp, c->p_o, D_MODEL, SK_OUT, c->part_o, c->part_ml, c->nsplit + 1, nb, st)); }
+        {
+          ProfScope ps(c, 1);
+          LAUNCH(launch_skinny_gemm_sb_combine(L.out_wp, c->p_o, D_MODEL, SK_OUT, c->part_o, c->part_ml, c->nsplit + 1, nb, st, c->qk_new));
+        }
       } else {
       {
         ProfScope ps(c, 1);

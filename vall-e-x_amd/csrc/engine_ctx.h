@@ -108,6 +108,7 @@ struct vx_ctx {
   bool mid_fuse = false;           // allow hc_chain (VX_MID_FUSE=1)
   bool sb_chain = false;           // the current micro-batch decodes on the small-batch chain (set by ar_prefill)
   bool sb_fuse = true;             // <= SB_ROWS rows: reduce+LN / combine folded into the consuming GEMM (VX_SB_FUSE=0: the general chain)
+  float* qk_new = nullptr;         // [MB][16][2][64]: q / 8 and k_new of the step's new token (dec_attn_qkv_kernel -> out_proj prologue)
   float *p_qkv = nullptr, *p_o = nullptr, *p_oh = nullptr, *p_logits = nullptr, *part_o = nullptr, *part_ml = nullptr;
   std::map<const unsigned short*, int> w_shift;   // f16x2: power-of-two scale exponent of every weight's planes
   unsigned short* fkv = nullptr;   // K | V of a NAR layer as attention-ready fp16 planes [4][Mmax + 256][1024] (f16x2 mode)

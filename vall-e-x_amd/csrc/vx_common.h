@@ -162,11 +162,13 @@ constexpr int SB_ROWS = 4;
 // sb_chain_supported: may the small-batch chain run with these split counts?  (otherwise the engine takes the general chain)
 bool sb_chain_supported(int sk_l2, int sk_out, int nsplit, int batch);
 // small batches with norm1 + the QKV projection folded into the split attention launch (decode.hip: dec_attn_qkv_kernel): grid
-// (head, slot, nsplit + 2); part_o / part_ml hold nsplit + 1 partials per (row, head).  skp = slabs of the previous layer's linear2
-// (partial_in, + pbias + resid -> LayerNorm with g, b; the workgroup of head 0, split 0 writes h_out), or 0: x is the packed image xp.
+// (head, slot, nsplit), nsplit in {4, 8, 16}; part_o / part_ml hold nsplit + 1 partials per (row, head) -- the last one is the new
+// token's: its output (v_new) is written here, its score q . k_new is formed by the consumer from qk_new [MB][16][2][64] = (q / 8, k_new)
+// (launch_skinny_gemm_sb_combine with nsplit + 1 and qk_new).  skp = slabs of the previous layer's linear2 (partial_in, + pbias +
+// resid -> LayerNorm with g, b; the workgroup of head 0, split 0 writes h_out), or 0: x is the packed image xp.
 bool sb_qkv_chain_supported(int sk_l2, int sk_out, int nsplit, int batch);
 bool launch_dec_attn_qkv(const float* in_w, const float* in_b, float* kc, float* vc, int Tmax, const int* slot_meta, float* part_o,
-                         float* part_ml, int nsplit, int batch, const float* partial_in, int skp, const float* pbias,
+                         float* part_ml, float* qk_new, int nsplit, int batch, const float* partial_in, int skp, const float* pbias,
                          const float* resid, float* h_out, const float* g, const float* b, const float* xp, hipStream_t s);
 // mid-size batches (2 .. 6 context splits): out_proj whose waves combine the context-split partials of THEIR head in the prologue
 bool hc_chain_supported(int sk_out, int nsplit);
@@ -178,7 +180,7 @@ bool launch_skinny_gemm_sb_ln(const float* Wp, float* partial_out, int Npad, int
                               hipStream_t s);
 // the same GEMM on the combine of dec_attn's context-split partials (out_proj, K = 1024)
 bool launch_skinny_gemm_sb_combine(const float* Wp, float* partial_out, int Npad, int splitk, const float* part_o, const float* part_ml,
-                                   int nsplit, int batch, hipStream_t s);
+                                   int nsplit, int batch, hipStream_t s, const float* qk_new = nullptr);
 // linear1 (bias + ReLU + pack fused, 16-row tiles) on LN(resid + sum of the out_proj slabs + pbias)
 bool launch_skinny16_sb_ln(const float* W16, const float* bias, float* xp_out, int N, const float* partial_in, int sk_in,
                            const float* pbias, const float* resid, float* h_out, const float* g, const float* b, int batch,

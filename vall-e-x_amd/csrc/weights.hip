@@ -157,6 +157,7 @@ int vx_finalize_weights(vx_ctx* c) {
   if ((e = dev_alloc(c, &c->p_logits, (size_t)SK_PRED * MB * PRED_NPAD))) return e;
   if ((e = dev_alloc(c, &c->part_o, (size_t)MB * N_HEAD * 16 * D_HEAD))) return e;
   if ((e = dev_alloc(c, &c->part_ml, (size_t)MB * N_HEAD * 16 * 2))) return e;
+  if ((e = dev_alloc(c, &c->qk_new, (size_t)MB * N_HEAD * 2 * D_HEAD))) return e;
   if ((e = dev_alloc(c, &c->d_logits, (size_t)MB * AR_LOGITS))) return e;
   if ((e = dev_alloc(c, &c->sum_logp, (size_t)MB))) return e;
   c->uniforms_cap = (long)(c->cfg.max_new + 2) * MB;
