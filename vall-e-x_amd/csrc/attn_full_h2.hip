@@ -103,13 +103,7 @@ __device__ __forceinline__ f32x2 exp_s2(f32x2 x) {
 #ifndef VX_ATTN_PRIO
 #define VX_ATTN_PRIO 0
 #endif
-// KVP: K and V arrive PRE-SPLIT (fp16 head / tail at scale 2^5, row-major [row][1024] per plane: kv[(2 * which + plane)][row][...],
-// which = 0 K, 1 V) -- written once per layer by the QKV GEMM's epilogue (gemm_f16x2.hip, GemmX3Args::kv_planes) with the very
-// conversions of split2_pair, instead of every one of a head's 8 query blocks splitting the same K / V tile again on its way into
-// LDS (~ 70 of the ~ 270 VALU instructions per key tile of this VALU-bound kernel).  Staging then is: K words straight into LDS, V
-// words through four v_perm_b32 per plane (the key pair of a V^T word comes from two rows).  Q is still read in fp32 (split once
-// per workgroup).  Same LDS image, same MFMA operands => bit-identical results.
-template <int PRIO, bool KVP>
+template <int PRIO>
 __global__ __launch_bounds__(256, 2) void attn_full_h2_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                              const int* __restrict__ seq_off,
                                                              const int* __restrict__ seq_len,
@@ -117,8 +111,7 @@ __global__ __launch_bounds__(256, 2) void attn_full_h2_kernel(const float* __res
                                                              unsigned short* __restrict__ planes, long plane_stride,
                                                              int* __restrict__ range_flag,
                                                              const int* __restrict__ q_first,
-                                                             const int* __restrict__ c_off,
-                                                             const unsigned short* __restrict__ kv, long kv_stride) {
+                                                             const int* __restrict__ c_off) {
   // q_first / c_off (planes mode only, optional): ROW TRIMMING for a layer whose output is only needed for the rows
   // [q_first[b], len) of every sequence (the last decoder layer of a NAR stage: only generated frames reach a predict layer,
   // models/vallex.py:672-679).  Query blocks that lie entirely before q_first[b] are skipped, and the output planes are written
@@ -183,41 +176,21 @@ __global__ __launch_bounds__(256, 2) void attn_full_h2_kernel(const float* __res
   // position of key 2 kp inside a V^T row: keys of (s, hi) = 16 s + 4 hi + {0,1,2,3,8,9,10,11} are positions 8 (2 s + hi) + j
   const int vpos = ((kp2 >> 4) * 2 + ((kp2 >> 2) & 1)) * 8 + (kp2 & 3) + 4 * ((kp2 >> 3) & 1);
   f32x4 rk[2], rv[2];
-  u32x2 pk[2][2], pv[2][2];                                    // KVP: staged plane words [float4 i / key][plane]: 4 fp16 each
   unsigned kw[2][2][2];                                        // split K of the staged tile: [float4 i][plane][pair]
   unsigned vw[4][2];                                           // split V: [dim e][plane] = (key 2 kp, key 2 kp + 1)
-  const unsigned short* kvb = KVP ? kv + row0 * (long)D_MODEL + h * D_HEAD + c4 : nullptr;
   auto issue = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       int kk = k0 + ((tid + 256 * i) >> 4);
       kk = kk < len ? kk : len - 1;
-      int kv_ = k0 + kp2 + i;
-      kv_ = kv_ < len ? kv_ : len - 1;
-      if constexpr (KVP) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          pk[i][p] = *reinterpret_cast<const u32x2*>(kvb + (long)p * kv_stride + kk * (long)D_MODEL);
-          pv[i][p] = *reinterpret_cast<const u32x2*>(kvb + (long)(2 + p) * kv_stride + kv_ * (long)D_MODEL);
-        }
-      } else {
-        rk[i] = *reinterpret_cast<const f32x4*>(kbase + kk * (long)(3 * D_MODEL) + c4);
-        rv[i] = *reinterpret_cast<const f32x4*>(vbase + kv_ * (long)(3 * D_MODEL) + c4);
-      }
+      rk[i] = *reinterpret_cast<const f32x4*>(kbase + kk * (long)(3 * D_MODEL) + c4);
+      int kv = k0 + kp2 + i;
+      kv = kv < len ? kv : len - 1;
+      rv[i] = *reinterpret_cast<const f32x4*>(vbase + kv * (long)(3 * D_MODEL) + c4);
     }
   };
-  auto split_k = [&](int i, int pr) {
-    if constexpr (KVP) { kw[i][0][pr] = pk[i][0][pr]; kw[i][1][pr] = pk[i][1][pr]; }
-    else split2_pair(f32x2{rk[i][2 * pr], rk[i][2 * pr + 1]} * QK_SCALE, kw[i][0][pr], kw[i][1][pr]);
-  };
-  auto split_v = [&](int e) {
-    if constexpr (KVP) {
-      // word e of a V^T row pair = (key 2 kp dim c4 + e | key 2 kp + 1 dim c4 + e << 16): halves e & 1 of words e >> 1 of the two rows
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-        vw[e][p] = __builtin_amdgcn_perm(pv[1][p][e >> 1], pv[0][p][e >> 1], (e & 1) ? 0x07060302u : 0x05040100u);
-    } else split2_pair(f32x2{rv[0][e], rv[1][e]} * V_SCALE, vw[e][0], vw[e][1]);
-  };
+  auto split_k = [&](int i, int pr) { split2_pair(f32x2{rk[i][2 * pr], rk[i][2 * pr + 1]} * QK_SCALE, kw[i][0][pr], kw[i][1][pr]); };
+  auto split_v = [&](int e) { split2_pair(f32x2{rv[0][e], rv[1][e]} * V_SCALE, vw[e][0], vw[e][1]); };
   auto write_k = [&](int buf, int i) {
     const int off = ((tid + 256 * i) >> 4) * KP_LD + c4 * 2;
 #pragma unroll
@@ -458,17 +431,11 @@ __global__ __launch_bounds__(256, 2) void attn_full_h2_kernel(const float* __res
 
 void launch_attn_full_h2(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
                          int batch, int max_len, hipStream_t s, unsigned short* planes, long plane_stride, int* range_flag,
-                         int prio, const int* q_first, const int* c_off, const unsigned short* kv, long kv_stride) {
+                         int prio, const int* q_first, const int* c_off) {
   if (batch <= 0 || max_len <= 0) return;
   const int nqb = (max_len + QB - 1) / QB;                   // batch * N_HEAD is a multiple of 8 (16 heads)
   const dim3 grid(nqb * N_HEAD * batch), block(256);
-#define VX_ATTN_H2_GO(P)                                                                                                         \
-  do {                                                                                                                           \
-    if (kv) hipLaunchKernelGGL((attn_full_h2_kernel<P, true>), grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, planes, \
-                               plane_stride, range_flag, planes ? q_first : nullptr, planes ? c_off : nullptr, kv, kv_stride);  \
-    else hipLaunchKernelGGL((attn_full_h2_kernel<P, false>), grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, planes,  \
-                            plane_stride, range_flag, planes ? q_first : nullptr, planes ? c_off : nullptr, kv, kv_stride);      \
-  } while (0)
+#define VX_ATTN_H2_GO(P) hipLaunchKernelGGL(attn_full_h2_kernel<P>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, planes, plane_stride, range_flag, planes ? q_first : nullptr, planes ? c_off : nullptr)
 #ifdef VX_DEV_PROBES
   static const int env_prio = [] { const char* e = getenv("VX_ATTN_PRIO_RT"); return e ? atoi(e) : -1; }();
   const int p = prio >= 0 ? prio : (env_prio >= 0 ? env_prio : VX_ATTN_PRIO);

@@ -1247,112 +1247,6 @@ void launch_dec_attn_combine(const float* part_o, const float* part_ml, int nspl
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Mid-size batches (5 .. 16 rows decode with 2 .. 6 context splits; BASELINE config 5 = 8 rows): out_proj with the context-split
-// combine of dec_attn in its OWN prologue, restricted to what each wave contracts.  With K = 1024 and split-K 4 the four waves of
-// workgroup (n-tile, ks) contract k = 64 (4 ks + wid) .. + 63: exactly ONE head each.  Lane (b = lane & 31, hi = lane >> 5) needs
-// x[b][64 head + 8 u + 4 hi ..+3], u < 8, i.e. float4 chunks 2u + hi of that head's combined output for ITS row -- which it
-// computes itself from the NS partials of (row b, head): NS x 8 float4 + NS float2 loads per lane out of L2, no LDS, no
-// barrier, while the wave's weight tile is already in flight.  (The 8-row fold tried in round 3 combined all 16 heads x 8 rows
-// in every workgroup -- 4x the loads plus an LDS image and a barrier -- and lost to the launch it removed.)  The arithmetic of an
-// element is dec_attn_combine_kernel's, operation for operation.  Removes one launch + boundary per layer.
-// ------------------------------------------------------------------------------------------------------------
-template <int NS>
-__global__ __launch_bounds__(256) void skinny_gemm_hc_kernel(const float* __restrict__ Wp, float* __restrict__ out,
-                                                             const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                                             int M) {
-  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
-  constexpr int K = D_MODEL, Npad = D_MODEL, KB = K / 8, SPLITK = 4, KBW = KB / (SPLITK * 4);
-  static_assert(KBW * 8 == D_HEAD, "a wave's K slice must be exactly one head");
-  const int nt = blockIdx.x, ks = blockIdx.y;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int head = ks * 4 + wid, kb0 = head * KBW;
-  const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + ((long)nt * KB + kb0) * 64 + lane;
-  f32x4 w[8], x[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + (long)u * 64);
-  const int b = lane & 31, hi = lane >> 5;
-  const bool row = b < M;
-#pragma unroll
-  for (int u = 0; u < 8; ++u) x[u] = f32x4{0.f, 0.f, 0.f, 0.f};          // rows >= M are zero columns of the MFMA
-  if (row) {
-    // ALL 8 NS + NS loads of the lane are requested together (one memory round trip: the partials were written by other CUs a
-    // kernel ago); only the lanes of live rows issue them
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const long pi = (long)(b * N_HEAD + head) * NS;
-    f32x2 ml[NS];
-    f32x4 po[8][NS];
-#pragma unroll
-    for (int sp = 0; sp < NS; ++sp) ml[sp] = *reinterpret_cast<const f32x2*>(part_ml + (pi + sp) * 2);
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-#pragma unroll
-      for (int sp = 0; sp < NS; ++sp) po[u][sp] = *reinterpret_cast<const f32x4*>(part_o + (pi + sp) * D_HEAD + (2 * u + hi) * 4);
-    // pin: every load above is requested before the first use below (the scheduler otherwise trades the single round trip for
-    // register pressure and walks the partials in batches)
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-#pragma unroll
-      for (int sp = 0; sp < NS; ++sp) asm volatile("" : "+v"(po[u][sp]));
-    float mt = NEG_BIG;
-#pragma unroll
-    for (int sp = 0; sp < NS; ++sp) mt = fmaxf(mt, ml[sp][0]);
-    float a[NS], lt = 0.f;
-#pragma unroll
-    for (int sp = 0; sp < NS; ++sp) {
-      a[sp] = expf(ml[sp][0] - mt);
-      lt += ml[sp][1] * a[sp];
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      f32x4 ot = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int sp = 0; sp < NS; ++sp)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ot[e] += po[u][sp][e] * a[sp];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) ot[e] = ot[e] / lt;
-      x[u] = ot;
-    }
-  }
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-  for (int u = 0; u < 8; ++u)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[u][j], x[u][j], acc, 0, 0, 0);
-  // epilogue of skinny_gemm_kernel
-#pragma unroll
-  for (int r = 0; r < 16; ++r) red[((wid * 16 + r) * 64) + lane] = acc[r];
-  __syncthreads();
-  f32x4 t;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float* rp = red + ((wid * 4 + j) * 64) + lane;
-    t[j] = ((rp[0] + rp[16 * 64]) + rp[2 * 16 * 64]) + rp[3 * 16 * 64];
-  }
-  float* dst = out + ((long)ks * MB + (lane & 31)) * Npad + nt * 32 + 4 * (lane >> 5);
-  *reinterpret_cast<f32x4*>(dst + wid * 8) = t;
-}
-
-bool hc_chain_supported(int sk_out, int nsplit) { return sk_out == 4 && nsplit >= 2 && nsplit <= 6; }
-
-// out_proj (N = K = 1024, split-K 4) on the combine of dec_attn's `nsplit` context-split partials; false = not instantiated
-bool launch_skinny_gemm_hc(const float* Wp, float* partial_out, int splitk, const float* part_o, const float* part_ml, int nsplit,
-                           int batch, hipStream_t s) {
-  if (splitk != 4) return false;
-#define VX_HC(NSV) hipLaunchKernelGGL((skinny_gemm_hc_kernel<NSV>), dim3(D_MODEL / 32, 4), dim3(256), 0, s, Wp, partial_out, part_o, part_ml, batch)
-  if (nsplit == 2) VX_HC(2);
-  else if (nsplit == 3) VX_HC(3);
-  else if (nsplit == 4) VX_HC(4);
-  else if (nsplit == 5) VX_HC(5);
-  else if (nsplit == 6) VX_HC(6);
-  else return false;
-#undef VX_HC
-  return true;
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // dec_sample: ar_predict_layer logits (split-K partials) -> topk_sampling (models/vallex.py:791-853) -> EOS / cap
 // bookkeeping (models/vallex.py:572-598), one block per row, everything stays on the device.
 // ------------------------------------------------------------------------------------------------------------

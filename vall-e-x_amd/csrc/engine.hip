@@ -53,8 +53,7 @@ void gemm(vx_ctx* c, const float* A, int lda, const float* Wt, int ldw, const fl
 // GEMM's A planes (K = N) instead of fp32 rows (C may then be null).
 void proj(vx_ctx* c, const float* A, int lda, const float* Wf, const unsigned short* W3, const float* bias,
           const float* resid, int ldr, float* C, int ldc, long M, int N, int K, int act, const int* gather = nullptr,
-          const unsigned short* a_pre = nullptr, unsigned short* out_pl = nullptr, const int* resid_rows = nullptr,
-          unsigned short* kv_planes = nullptr, long kv_stride = 0) {
+          const unsigned short* a_pre = nullptr, unsigned short* out_pl = nullptr, const int* resid_rows = nullptr) {
   if (c->gemm_mode == 2 || !W3) {
     gemm(c, A, lda, Wf, K, bias, resid, ldr, nullptr, C, ldc, M, N, K, act, gather, 2);
     return;
@@ -70,7 +69,6 @@ void proj(vx_ctx* c, const float* A, int lda, const float* Wf, const unsigned sh
   g.colscale = nullptr; g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.act = act;
   g.out_planes = out_pl; g.out_plane = out_pl ? h2_plane(M, N, H2_TILE_A) : 0; g.range_flag = c->range_flag;
   g.resid_rows = resid_rows;                     // f16x2 kernel only (the one mode that trims rows)
-  g.kv_planes = kv_planes; g.kv_stride = kv_stride;
   if (c->gemm_mode == 0) g.descale = ldexpf(1.0f, -(H2_ACT_SHIFT + c->w_shift.at(W3)));
   ProfScope ps(c, 2);
   if (c->prof_on) c->prof[2].bytes += 2.0 * (double)M * N * K;
@@ -102,11 +100,8 @@ int full_layer(vx_ctx* c, const LayerW& L, long M, const int* seq_off, const int
   const long pl1024 = h2_plane(M, D_MODEL, H2_TILE_A);
   launch_layernorm(c->fx, D_MODEL, pl ? nullptr : c->fxn, D_MODEL, (int)M, D_MODEL, LN_EPS, L.n1_w, L.n1_b, ada1,
                    ada1 ? ada1 + D_MODEL : nullptr, c->stream, pl ? c->fa3 : nullptr, pl1024, c->range_flag);
-  // NAR layers (no KV cache to fill): the QKV GEMM hands K and V to the attention kernel already split into its fp16 operand planes
-  const bool kvp = c->kv_planes_on && c->fkv && !kcl && pl && c->attn_x3 && c->attn_h2;
-  const long kv_stride = (c->Mmax + 256) * (long)D_MODEL;
   proj(c, c->fxn, D_MODEL, L.in_w, L.in_w3, L.in_b, nullptr, 0, c->fqkv, 3 * D_MODEL, M, 3 * D_MODEL, D_MODEL, ACT_NONE, nullptr,
-       pl ? c->fa3 : nullptr, nullptr, nullptr, kvp ? c->fkv : nullptr, kv_stride);
+       pl ? c->fa3 : nullptr);
   if (kcl) launch_kv_scatter(c->fqkv, row_b, row_t, (int)M, kcl, vcl, c->Tmax, c->stream);
   const bool att_pl = pl && c->attn_x3;
   if (tr) {                                        // caller guarantees f16x2 projections + f16x2 attention
@@ -115,7 +110,7 @@ int full_layer(vx_ctx* c, const LayerW& L, long M, const int* seq_off, const int
       ProfScope ps(c, 3);
       if (c->prof_on) c->prof[3].bytes += tr->attn_flops;
       launch_attn_full_h2(c->fqkv, nullptr, seq_off, seq_len, prefix_len, batch, max_len, c->stream, c->fa3, plc, c->range_flag, -1,
-                          tr->q_first, tr->c_off, kvp ? c->fkv : nullptr, kv_stride);
+                          tr->q_first, tr->c_off);
     }
     // x' = x[kept rows] + out_proj(attention): residual read through the row map, result compacted in fxn
     proj(c, nullptr, D_MODEL, L.out_w, L.out_w3, L.out_b, c->fx, D_MODEL, c->fxn, D_MODEL, tr->Mc, D_MODEL, D_MODEL, ACT_NONE, nullptr,
@@ -131,7 +126,7 @@ int full_layer(vx_ctx* c, const LayerW& L, long M, const int* seq_off, const int
     if (c->prof_on) c->prof[3].bytes += attn_flops;
     if (c->attn_x3 && c->attn_h2)
       launch_attn_full_h2(c->fqkv, att_pl ? nullptr : c->fatt, seq_off, seq_len, prefix_len, batch, max_len, c->stream,
-                          att_pl ? c->fa3 : nullptr, pl1024, c->range_flag, -1, nullptr, nullptr, kvp ? c->fkv : nullptr, kv_stride);
+                          att_pl ? c->fa3 : nullptr, pl1024, c->range_flag);
     else if (c->attn_x3)
       launch_attn_full_x3(c->fqkv, att_pl ? nullptr : c->fatt, seq_off, seq_len, prefix_len, batch, max_len, 0, c->stream,
                           att_pl ? c->fa3 : nullptr, pl1024);
@@ -282,10 +277,9 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
   c->nsplit = std::max(1, std::min(16, 512 / (nrows * N_HEAD)));
   // the small-batch chain compiles the split counts in (decode.hip): taken only for a combination that is instantiated
   c->sb_chain = false;
-  c->hc_chain = c->mid_fuse && c->nsplit > 1 && hc_chain_supported(SK_OUT, c->nsplit);
   if (c->sb_fuse && nrows <= SB_ROWS) {
     const int ns = nrows <= 2 ? 16 : 8;
-    if (sb_chain_supported(SK_L2, SK_OUT, ns, nrows)) { c->nsplit = ns; c->sb_chain = true; c->hc_chain = false; }
+    if (sb_chain_supported(SK_L2, SK_OUT, ns, nrows)) { c->nsplit = ns; c->sb_chain = true; }
     // ... with norm1 + QKV inside the attention launch for the smallest batches (VX_SB_QKV=<max rows>; its split count is tunable)
     c->sb_qkv = false;
     if (c->sb_chain && nrows <= c->sb_qkv_rows) {
@@ -434,13 +428,8 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
     if (fused) {
       launch_dec_reduce_ln_pack(c->p_oh, N_HEAD, D_MODEL, L.out_b, c->dh, c->dh, L.n2_w, L.n2_b, c->xp, nb, st);
     } else {
-      if (c->hc_chain) {      // 5 .. 16 rows: the combine runs in the out_proj GEMM's prologue, per wave = per head (decode.hip)
-        ProfScope ps(c, 1);
-        LAUNCH(launch_skinny_gemm_hc(L.out_wp, c->p_o, SK_OUT, c->part_o, c->part_ml, c->nsplit, nb, st));
-      } else {
-        if (c->nsplit > 1) launch_dec_attn_combine(c->part_o, c->part_ml, c->nsplit, c->active, c->xp_att, nb, st);
-        { ProfScope ps(c, 1); launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, st); }
-      }
+      if (c->nsplit > 1) launch_dec_attn_combine(c->part_o, c->part_ml, c->nsplit, c->active, c->xp_att, nb, st);
+      { ProfScope ps(c, 1); launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, st); }
       launch_dec_reduce_ln_pack(c->p_o, SK_OUT, D_MODEL, L.out_b, c->dh, c->dh, L.n2_w, L.n2_b, c->xp, nb, st);
     }
     { ProfScope ps(c, 1); launch_skinny16_relu_pack(L.l1_wp, c->xp, L.l1_b, c->xp4, D_FF, D_MODEL, st); }
@@ -557,7 +546,7 @@ int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int 
     }
   }
   char sig[160];
-  snprintf(sig, sizeof sig, "b%d ns%d c%d%d%d k%d t%a u%d f%d l%d", nb, c->nsplit, (int)c->sb_chain, (int)c->hc_chain, (int)c->sb_qkv, sa.top_k, sa.temperature,
+  snprintf(sig, sizeof sig, "b%d ns%d c%d%d k%d t%a u%d f%d l%d", nb, c->nsplit, (int)c->sb_chain, (int)c->sb_qkv, sa.top_k, sa.temperature,
            sa.uniforms != nullptr, sa.force_eos_at, sa.sum_logp != nullptr);
   const int sync_every = s->sync_every > 0 ? s->sync_every : 8;
   // with a forced EOS every row is inactive after force_eos_at steps: do not run on to the next host poll

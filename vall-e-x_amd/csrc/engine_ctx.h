@@ -104,15 +104,11 @@ struct vx_ctx {
   float *dh = nullptr, *dh2 = nullptr, *xp = nullptr, *xp_att = nullptr, *xp4 = nullptr;
   bool sb_qkv = false;             // ... on the small-batch chain with norm1 + QKV folded into the attention launch
   int sb_qkv_rows = 4, sb_qkv_nsplit = 0;   // sb_qkv up to this many rows (VX_SB_QKV=n, 0 = off), forced split count (VX_SB_QKV_NSPLIT)
-  bool hc_chain = false;           // ... on the mid-size chain: out_proj combines the context splits per head in its prologue
-  bool mid_fuse = false;           // allow hc_chain (VX_MID_FUSE=1)
   bool sb_chain = false;           // the current micro-batch decodes on the small-batch chain (set by ar_prefill)
   bool sb_fuse = true;             // <= SB_ROWS rows: reduce+LN / combine folded into the consuming GEMM (VX_SB_FUSE=0: the general chain)
   float* qk_new = nullptr;         // [MB][16][2][64]: q / 8 and k_new of the step's new token (dec_attn_qkv_kernel -> out_proj prologue)
   float *p_qkv = nullptr, *p_o = nullptr, *p_oh = nullptr, *p_logits = nullptr, *part_o = nullptr, *part_ml = nullptr;
   std::map<const unsigned short*, int> w_shift;   // f16x2: power-of-two scale exponent of every weight's planes
-  unsigned short* fkv = nullptr;   // K | V of a NAR layer as attention-ready fp16 planes [4][Mmax + 256][1024] (f16x2 mode)
-  bool kv_planes_on = false;       // the QKV GEMM writes them, attn_full_h2 stages them (VX_KV_PLANES=1)
   bool nar_trim = true;            // last NAR layer computes only the generated rows (VX_NAR_TRIM=1; engine.hip struct Trim)
   bool balance_rows = true;        // dec_attn launch order pairs long with short contexts per CU (VX_BALANCE_ROWS=0: batch order)
   bool fuse_out = true;            // out_proj folded into dec_attn when nsplit == 1 (VX_FUSE_OUT=0: separate skinny GEMM)

@@ -359,7 +359,6 @@ __global__ __launch_bounds__(TM * 2, (TM == 256 || NST == 4) ? 1 : 2) void gemm_
   // activations nor a split pass.  The 32 columns of a (jn) block are exactly one K tile of the consumer; lanes l and l ^ 32 hold
   // complementary 4-column halves of each 8-column group, so they trade halves (one ds_bpermute per word) and every lane stores
   // 16 contiguous bytes per plane.  Same conversions as split2h_kernel => bit-identical planes.
-  const bool kv_tile = g.kv_planes != nullptr && n0 >= D_MODEL;           // uniform over the workgroup (tiles never straddle 1024)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + wm * 64 + i * 32 + l31;
@@ -390,7 +389,7 @@ __global__ __launch_bounds__(TM * 2, (TM == 256 || NST == 4) ? 1 : 2) void gemm_
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = rr[e] + v[e];
         }
-        if (!g.out_planes && !kv_tile) {
+        if (!g.out_planes) {
           *reinterpret_cast<f32x4*>(g.C + (long)m * g.ldc + n) = v;
         } else {
 #pragma unroll
@@ -409,29 +408,7 @@ __global__ __launch_bounds__(TM * 2, (TM == 256 || NST == 4) ? 1 : 2) void gemm_
           }
         }
       }
-      if (kv_tile) {
-        // K | V columns of the QKV projection as the row-major fp16 planes attn_full_h2 stages (GemmX3Args::kv_planes): same lane
-        // exchange as below, 16 contiguous bytes (8 columns) per lane and plane
-        const int nb0 = n0 + wn * (TN / 2) + jn * 32;                       // first column of this 32-column block (>= 1024)
-        const int which = nb0 / D_MODEL - 1;
-        unsigned short* base = g.kv_planes + (long)(2 * which) * g.kv_stride + (long)m * D_MODEL + (nb0 - (which + 1) * D_MODEL);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int keep = 2 * j + hi, give = 2 * j + 1 - hi;
-          unsigned rh[2], rt[2];
-#pragma unroll
-          for (int q = 0; q < 2; ++q) {
-            rh[q] = (unsigned)__shfl_xor((int)hw[give][q], 32, 64);
-            rt[q] = (unsigned)__shfl_xor((int)tw[give][q], 32, 64);
-          }
-          typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-          const u32x4v oh = hi ? u32x4v{rh[0], rh[1], hw[keep][0], hw[keep][1]} : u32x4v{hw[keep][0], hw[keep][1], rh[0], rh[1]};
-          const u32x4v ot = hi ? u32x4v{rt[0], rt[1], tw[keep][0], tw[keep][1]} : u32x4v{tw[keep][0], tw[keep][1], rt[0], rt[1]};
-          *reinterpret_cast<u32x4v*>(base + 16 * j + 8 * hi) = oh;
-          *reinterpret_cast<u32x4v*>(base + 16 * j + 8 * hi + g.kv_stride) = ot;
-        }
-        if (bad && g.range_flag) *g.range_flag = 1;
-      } else if (g.out_planes) {
+      if (g.out_planes) {
         // consumer plane element (m, k = n): ((m / 256) * (N / 32) + n / 32) * 256 * 32 + (m % 256) * 32 + n % 32
         const long blk = ((long)(m0 / HM) * (g.N / HK) + (n0 + wn * (TN / 2) + jn * 32) / HK) * (HM * HK) +
                          (long)(m0 % HM + wm * 64 + i * 32 + l31) * HK;

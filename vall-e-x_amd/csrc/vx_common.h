@@ -54,9 +54,6 @@ struct GemmX3Args {
   unsigned short* out_planes; long out_plane;   // plane stride in elements: h2_plane(M, N, H2_TILE_A)
   int* range_flag;
   float descale;                                // f16x2: 2^-(shift of A + shift of W), applied to the accumulator (exact)
-  // f16x2 only, optional (the QKV projection of a NAR layer): columns n >= 1024 (K | V) are NOT written as fp32 but as the fp16 head /
-  // tail planes attn_full_h2 stages, kv_planes[(2 * which + plane) * kv_stride + m * 1024 + n % 1024], which = n / 1024 - 1, scale 2^5
-  unsigned short* kv_planes; long kv_stride;
   const int* resid_rows;                        // f16x2 only, optional: row of `resid` for output row m (null = m): compacted row sets
   int dev_variant;                              // benchmarks: 3 = the staggered schedule (STG) of the 256 x 256 kernel, -1 = the plain one;
                                                 // 1 / 2 = its wave-priority variants (tools builds only); 0 = the product's choice
@@ -137,8 +134,7 @@ void launch_attn_full_x3(const float* qkv, float* out, const int* seq_off, const
 void launch_attn_full_h2(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
                          int batch, int max_len, hipStream_t s, unsigned short* planes, long plane_stride, int* range_flag,
                          int prio = -1,       // prio >= 0: wave-priority variant (tools builds only; see the kernel)
-                         const int* q_first = nullptr, const int* c_off = nullptr,    // row trimming (planes mode; see the kernel)
-                         const unsigned short* kv = nullptr, long kv_stride = 0);     // K / V pre-split by the QKV GEMM (see the kernel)
+                         const int* q_first = nullptr, const int* c_off = nullptr);   // row trimming (planes mode; see the kernel)
 #ifdef VX_DEV_PROBES
 void launch_attn_full_probe(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
                             int batch, int max_len, int variant, hipStream_t s);   // timing probes (tools/attn_bench.py)
@@ -171,10 +167,6 @@ bool sb_qkv_chain_supported(int sk_l2, int sk_out, int nsplit, int batch);
 bool launch_dec_attn_qkv(const float* in_w, const float* in_b, float* kc, float* vc, int Tmax, const int* slot_meta, float* part_o,
                          float* part_ml, float* qk_new, int nsplit, int batch, const float* partial_in, int skp, const float* pbias,
                          const float* resid, float* h_out, const float* g, const float* b, const float* xp, hipStream_t s);
-// mid-size batches (2 .. 6 context splits): out_proj whose waves combine the context-split partials of THEIR head in the prologue
-bool hc_chain_supported(int sk_out, int nsplit);
-bool launch_skinny_gemm_hc(const float* Wp, float* partial_out, int splitk, const float* part_o, const float* part_ml, int nsplit,
-                           int batch, hipStream_t s);
 // partial_out[ks][b][n] = sum_k LN(resid[b] + sum_ks' partial_in[ks'][b] + bias)[k] W[n][k]   (K = 1024); workgroup 0 writes h_out
 bool launch_skinny_gemm_sb_ln(const float* Wp, float* partial_out, int Npad, int splitk, const float* partial_in, int sk_in,
                               const float* bias, const float* resid, float* h_out, const float* g, const float* b, int batch,

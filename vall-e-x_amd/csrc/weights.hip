@@ -150,7 +150,6 @@ int vx_finalize_weights(vx_ctx* c) {
   if (const char* ev = getenv("VX_FUSE_OUT")) c->fuse_out = !(ev[0] == '0');
   if (const char* ev = getenv("VX_BALANCE_ROWS")) c->balance_rows = !(ev[0] == '0');
   if (const char* ev = getenv("VX_NAR_TRIM")) c->nar_trim = ev[0] == '1';
-  if (const char* ev = getenv("VX_MID_FUSE")) c->mid_fuse = ev[0] == '1';
   if (const char* ev = getenv("VX_GRAPH_MULTI")) c->graph_multi = !(ev[0] == '0');
   if (const char* ev = getenv("VX_SB_QKV")) c->sb_qkv_rows = atoi(ev);
   if (const char* ev = getenv("VX_SB_QKV_NSPLIT")) c->sb_qkv_nsplit = atoi(ev);
@@ -227,10 +226,6 @@ int vx_finalize_weights(vx_ctx* c) {
       if ((e = split_w(W(c, "nar_predict_layers." + std::to_string(j) + ".weight"), AUDIO_VOCAB, d, &c->pred_w3[j]))) return e;
     if ((e = dev_alloc(c, &c->fa3, (size_t)P * (c->Mmax + 256) * f))) return e;       // zeroed: the pad rows of a last tile are read
     if (c->gemm_mode == 0 && (e = dev_alloc(c, &c->fa3b, (size_t)2 * (c->Mmax + 256) * f))) return e;
-    if (const char* ev = getenv("VX_KV_PLANES")) c->kv_planes_on = ev[0] == '1';
-    if (c->gemm_mode == 0 && c->attn_x3 && c->attn_h2 && c->kv_planes_on &&
-        (e = dev_alloc(c, &c->fkv, (size_t)4 * (c->Mmax + 256) * d)))
-      return e;
   }
 
   // ---- packed decode images of the AR stack ----
