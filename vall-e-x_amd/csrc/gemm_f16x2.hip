@@ -114,20 +114,8 @@ void launch_absmax(const float* x, long n, unsigned* out_bits, hipStream_t s) {
 #ifndef VX_GEMM_PRIO
 #define VX_GEMM_PRIO 0
 #endif
-#ifndef VX_GEMM_STG_DEFAULT
-#define VX_GEMM_STG_DEFAULT false     // the staggered schedule (template parameter STG) unless VX_GEMM_STG says otherwise
-#endif
-// STG (256 x 256 tile): STAGGERED wave groups.  In the plain schedule all eight waves of the CU read fragments at the same time and
-// multiply at the same time, so the two waves of a SIMD leave its matrix pipe idle during every LDS round trip (twice per K tile).
-// Here the second-dispatched half of the waves (group B, one wave per SIMD) runs one MFMA block (a k16 step, 24 MFMAs) behind
-// the first half (group A): while A multiplies, B reads its fragments, and vice versa.  One fragment set per wave (no extra
-// registers): a group's reads follow the ISSUE of its previous block's MFMAs.  The per-tile barrier sits at a different place
-// in the two groups' programs -- A passes it between M(t-1, 1) and R(t, 0), B between R(t-1, 1) and M(t-1, 1) -- so both arrive
-// together, every wave executes exactly K / 32 barriers, and the LDS-DMA requests of tile t + 1 (issued behind barrier t, into the
-// stage tile t - 1 just left) keep a full tile of lead.  Same MFMA sequence per accumulator => bit-identical sums.
-template <int TN, int TM, int NST = 2, int PRIO = 0, bool STG = false>
+template <int TN, int TM, int NST = 2, int PRIO = 0>
 __global__ __launch_bounds__(TM * 2, (TM == 256 || NST == 4) ? 1 : 2) void gemm_f16x2_kernel(GemmX3Args g) {
-  static_assert(!STG || (TN == 256 && TM == 256 && NST == 2), "the staggered schedule is written for the 256 x 256 tile");
   constexpr int NWAVE = TM / 32;                                                 // 8 / 4 waves: TM / 64 along M x 2 along N
   constexpr int HA_PL = TM * HLD;                                                // 16 / 8 KiB per A plane and stage
   constexpr int HN = TN, HW_PL = TN * HLD, HSTAGE = 2 * HA_PL + 2 * HW_PL;     // 64 / 48 / 32 KiB per stage
@@ -307,41 +295,6 @@ __global__ __launch_bounds__(TM * 2, (TM == 256 || NST == 4) ? 1 : 2) void gemm_
       if (kt + 2 < nk) step(kt + 2, 2);
       if (kt + 3 < nk) step(kt + 3, 3);
     }
-  } else if constexpr (STG) {
-    dma(stage0, 0);
-    if (wid < NWAVE / 2) {
-      // group A: barrier t | R(t, 0) M(t, 0) R(t, 1) M(t, 1); requests 0..3 / 4..7 of tile t + 1 behind M(t, 0) / M(t, 1)
-      auto a_tile = [&](const unsigned char* S, unsigned char* O, int kt) {
-        rendezvous();
-        frags(S, 0, w0, a0);
-        kstep16(w0, a0, O, kt + 1, kt + 1 < nk, 0);
-        frags(S, 1, w0, a0);
-        kstep16(w0, a0, O, kt + 1, kt + 1 < nk, 1);
-      };
-      for (int kt = 0; kt < nk; kt += 2) {
-        a_tile(stage0, stage1, kt);
-        if (kt + 1 < nk) a_tile(stage1, stage0, kt + 1);
-      }
-    } else {
-      // group B, one MFMA block behind: barrier t | M(t - 1, 1) R(t, 0) M(t, 0) R(t, 1); the fragments of M(t - 1, 1) were read
-      // before the barrier; requests 0..3 / 4..7 of tile t + 1 behind M(t - 1, 1) / M(t, 0)
-      auto b_tile = [&](const unsigned char* S, unsigned char* O, int kt) {
-        rendezvous();
-        if (kt > 0) kstep16(w0, a0, O, kt + 1, kt + 1 < nk, 0);
-        else if (nk > 1) {                                             // no M(-1, 1) to thread the first four requests into
-#pragma unroll
-          for (int j = 0; j < 4; ++j) dma1(O, 1, j);
-        }
-        frags(S, 0, w0, a0);
-        kstep16(w0, a0, O, kt + 1, kt + 1 < nk, 1);
-        frags(S, 1, w0, a0);
-      };
-      for (int kt = 0; kt < nk; kt += 2) {
-        b_tile(stage0, stage1, kt);
-        if (kt + 1 < nk) b_tile(stage1, stage0, kt + 1);
-      }
-      kstep16(w0, a0, nullptr, 0, false, 0);                           // M(nk - 1, 1)
-    }
   } else {
   dma(stage0, 0);
   for (int kt = 0; kt < nk; kt += 2) {
@@ -457,11 +410,6 @@ void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s, int tn) {
   if (two_stage) tm = 128;
   const int tiles = ((g.M + tm - 1) / tm) * ((g.N + tn - 1) / tn);
   if (tiles <= 0) return;
-  static const bool env_stg = [] { const char* e = getenv("VX_GEMM_STG"); return e ? e[0] == '1' : VX_GEMM_STG_DEFAULT; }();
-  if (tn == 256 && (g.dev_variant == 3 || (g.dev_variant == 0 && env_stg))) {
-    hipLaunchKernelGGL((gemm_f16x2_kernel<256, 256, 2, 0, true>), dim3(tiles), dim3(512), 0, s, g);
-    return;
-  }
 #ifdef VX_DEV_PROBES
   static const int env_prio = [] { const char* e = getenv("VX_GEMM_PRIO_RT"); return e ? atoi(e) : -1; }();
   const int prio = g.dev_variant > 0 ? g.dev_variant : (env_prio >= 0 ? env_prio : VX_GEMM_PRIO);

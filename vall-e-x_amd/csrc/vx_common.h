@@ -55,8 +55,7 @@ struct GemmX3Args {
   int* range_flag;
   float descale;                                // f16x2: 2^-(shift of A + shift of W), applied to the accumulator (exact)
   const int* resid_rows;                        // f16x2 only, optional: row of `resid` for output row m (null = m): compacted row sets
-  int dev_variant;                              // benchmarks: 3 = the staggered schedule (STG) of the 256 x 256 kernel, -1 = the plain one;
-                                                // 1 / 2 = its wave-priority variants (tools builds only); 0 = the product's choice
+  int dev_variant;                              // tools builds only (-DVX_DEV_PROBES): > 0 selects a wave-priority variant of the 256 x 256 kernel
 };
 void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s, int tn = 0);     // 256 x (256 | 128) x 32 tiles, async LDS fill, any M
 // f16x2 planes are TILE-major: [rows / tile_rows][K/32][tile_rows][32], tile_rows = 256 (both operands);
