@@ -4,7 +4,7 @@
 RND="${1:-03}"
 R="${GRAFT_REPO_ROOT:-$PWD}"; cd "$R" || exit 1
 mkdir -p gpurun_out
-CMD="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile"
+CMD="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --no-ref-arith"
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_kt" -o kt -- $CMD > "$R/gpurun_out/ev_kt.log" 2>&1; echo "kernel-trace rc=$?"
 DB=$(find "$R/gpurun_out/prof_kt" -name '*.db' | head -1)

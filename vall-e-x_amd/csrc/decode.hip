@@ -76,27 +76,9 @@ void dev_clear_stamps() {
 #endif
 
 // output: raw split-K partial slab [ks][b][n] (row-major per batch row; consumers: dec_attn, dec_reduce_ln_pack, dec_sample)
-// pf_q (optional, small-batch chain only): 32 extra workgroups (blockIdx.y == splitk) pull the q rows of the NEXT layer's in_proj --
-// the weights on the critical path of dec_attn_qkv_kernel, 16 heads x 256 KB -- into the L2 of the XCD that will contract them
-// (workgroup id % 8 == head % 8 in both launches), while this launch streams its own weights non-temporally.
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restrict__ Wp, const float* __restrict__ xp,
-                                                          float* __restrict__ out, int Npad, int K, int splitk,
-                                                          const float* __restrict__ pf_q) {
+                                                          float* __restrict__ out, int Npad, int K, int splitk) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
-  if ((int)blockIdx.y >= splitk) {
-    const int x = blockIdx.x, h = (x & 7) + 8 * ((x >> 3) & 1), half = x >> 4;
-    if (half > 1 || pf_q == nullptr) return;
-    const f32x4* src = reinterpret_cast<const f32x4*>(pf_q) + ((long)(h * D_HEAD + half * 32) * D_MODEL) / 4 + threadIdx.x;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-    for (int i = 0; i < 32; ++i) {
-      const f32x4 v = src[i * 256];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] += v[e];
-    }
-    asm volatile("" ::"v"(acc));                                 // the loads must happen; their values are not needed
-    return;
-  }
   const int stype_ = Npad == 3 * D_MODEL ? 0 : (Npad == D_MODEL ? 1 : 2);
   (void)stype_;
   VX_STAMP(stype_, 0);
@@ -158,11 +140,8 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
 }
 
 void launch_skinny_gemm(const float* Wp, const float* xp, float* partial, int Npad, int K, int splitk,
-                        hipStream_t s, const float* prefetch_q) {
-  // the prefetch workgroups need Npad / 32 >= 32 columns of workgroups (N = 1024: exactly the 32 that map onto 16 heads x 2 halves)
-  const bool pf = prefetch_q != nullptr && Npad / 32 >= 32;
-  hipLaunchKernelGGL(skinny_gemm_kernel, dim3(Npad / 32, splitk + (pf ? 1 : 0)), dim3(256), 0, s, Wp, xp, partial, Npad, K, splitk,
-                     pf ? prefetch_q : nullptr);
+                        hipStream_t s) {
+  hipLaunchKernelGGL(skinny_gemm_kernel, dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, xp, partial, Npad, K, splitk);
 }
 
 // ------------------------------------------------------------------------------------------------------------

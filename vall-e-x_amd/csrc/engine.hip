@@ -406,11 +406,7 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
         LAUNCH(launch_skinny16_sb_ln(L.l1_wp, L.l1_b, c->xp4, D_FF, c->p_o, SK_OUT, L.out_b, hr, hw, L.n2_w, L.n2_b, nb, st));
         std::swap(hr, hw);
       }
-      {
-        ProfScope ps(c, 1);
-        launch_skinny_gemm(L.l2_wp, c->xp4, c->p_o, D_MODEL, D_FF, SK_L2, st,
-                           (c->sb_qkv && c->sb_prefetch && l + 1 < NL) ? c->ar[l + 1].in_w : nullptr);
-      }
+      { ProfScope ps(c, 1); launch_skinny_gemm(L.l2_wp, c->xp4, c->p_o, D_MODEL, D_FF, SK_L2, st); }
     }
     {
       ProfScope ps(c, 1);

@@ -102,7 +102,6 @@ struct vx_ctx {
   // decode arena
   float *kc = nullptr, *vc = nullptr;      // [NL][mbr*16][Tmax][64]
   float *dh = nullptr, *dh2 = nullptr, *xp = nullptr, *xp_att = nullptr, *xp4 = nullptr;
-  bool sb_prefetch = false;        // linear2 of the sb_qkv chain prefetches the next layer's q rows into L2 (VX_SB_PREFETCH=1)
   bool sb_qkv = false;             // ... on the small-batch chain with norm1 + QKV folded into the attention launch
   int sb_qkv_rows = 4, sb_qkv_nsplit = 0;   // sb_qkv up to this many rows (VX_SB_QKV=n, 0 = off), forced split count (VX_SB_QKV_NSPLIT)
   bool sb_chain = false;           // the current micro-batch decodes on the small-batch chain (set by ar_prefill)

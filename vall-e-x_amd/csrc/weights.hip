@@ -151,7 +151,6 @@ int vx_finalize_weights(vx_ctx* c) {
   if (const char* ev = getenv("VX_BALANCE_ROWS")) c->balance_rows = !(ev[0] == '0');
   if (const char* ev = getenv("VX_NAR_TRIM")) c->nar_trim = ev[0] == '1';
   if (const char* ev = getenv("VX_GRAPH_MULTI")) c->graph_multi = !(ev[0] == '0');
-  if (const char* ev = getenv("VX_SB_PREFETCH")) c->sb_prefetch = ev[0] == '1';
   if (const char* ev = getenv("VX_SB_QKV")) c->sb_qkv_rows = atoi(ev);
   if (const char* ev = getenv("VX_SB_QKV_NSPLIT")) c->sb_qkv_nsplit = atoi(ev);
   if ((e = dev_alloc(c, &c->p_logits, (size_t)SK_PRED * MB * PRED_NPAD))) return e;
