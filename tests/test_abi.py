@@ -100,3 +100,18 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+
+
+def test_library_sources_never_abort_the_host_process():
+    """a C-ABI library reports VX_E* and a message; it must not contain abort() / exit() / assert() in host code paths (round 3
+    had five abort() calls in launchers: a split count that was not compiled in killed the caller)"""
+    import glob
+    bad = []
+    for f in glob.glob(os.path.join(ROOT, "vall-e-x_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "vall-e-x_amd", "csrc", "*.h")):
+        src = re.sub(r"//.*", "", open(f).read())
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        for m in re.finditer(r"(?<![A-Za-z_])(abort|exit|_Exit|quick_exit|assert)\s*\(", src):
+            if m.group(1) == "assert" and "static_assert" in src[max(0, m.start() - 7):m.end()]:
+                continue
+            bad.append((os.path.basename(f), m.group(0)))
+    assert not bad, bad
