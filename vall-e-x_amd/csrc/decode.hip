@@ -950,6 +950,15 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
 // packed image the sampler left.  (First version, measured in profiles/r04_sb_qkv_ab.log: two extra workgroups per (head, row) for
 // k_new / v_new; the one with q AND k_new to contract set the kernel's duration, 10.8 us at one row.)
 // ------------------------------------------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only: this wave's LDS writes are complete (lgkmcnt), then s_barrier.  __syncthreads()
+// carries a workgroup-scope fence that the compiler implements as s_waitcnt vmcnt(0): in dec_attn_qkv_kernel every barrier of the
+// LayerNorm prologue would wait for the 256 KB of weight rows requested before it.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 template <int SKP, int NSPL>
 __global__ __launch_bounds__(ATT_WAVES * 64, 2) void dec_attn_qkv_kernel(
     const float* __restrict__ in_w, const float* __restrict__ in_b, float* __restrict__ kc, float* __restrict__ vc, int Tmax,
@@ -973,14 +982,75 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void dec_attn_qkv_kernel(
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, gq = lane >> 4, c = lane & 15;
   const int ctx = meta[1], npast = ctx - 1;
   const long head_base = ((long)(b * N_HEAD + h) * Tmax) * D_HEAD;
+  // Order of the requests = order of need.  A CU's vector-memory path serves its waves' requests in order (~64 B per clock): the 12
+  // small loads of the LayerNorm prologue go FIRST, then the 256 KB of q rows (which the prologue's latency then hides), and the first
+  // K/V tile only behind the prologue -- it is needed after q.  (With the weight rows in front, the prologue's loads waited ~2 us in
+  // the queue behind them.)
+  const int tt = threadIdx.x;
+  const bool team = tt < 256;                                 // the LayerNorm team (thread tt owns float4 column tt)
+  f32x4 p[SKP > 0 ? SKP : 1], gg = {0.f, 0.f, 0.f, 0.f}, be = gg, rr = gg, bi = gg, x0 = gg;
+  if (SKP > 0) {
+    if (team) {
+      const int cc = tt * 4;
+#pragma unroll
+      for (int ks = 0; ks < SKP; ++ks) p[ks] = *reinterpret_cast<const f32x4*>(partial_in + ((long)ks * MB + b) * D_MODEL + cc);
+      rr = *reinterpret_cast<const f32x4*>(resid + (long)b * D_MODEL + cc);
+      bi = *reinterpret_cast<const f32x4*>(pbias + cc);
+      gg = *reinterpret_cast<const f32x4*>(g + cc);
+      be = *reinterpret_cast<const f32x4*>(bb + cc);
+    }
+  } else if (team) {
+    // layer 0: the sampler (or dec_embed_ln_pack) left norm1(h) in the packed image: float4 column c4 -> (c4 >> 1) * 64 + b + 32 (c4 & 1)
+    x0 = *(reinterpret_cast<const f32x4*>(xp) + ((long)(tt >> 1) * 64 + b + 32 * (tt & 1)));
+  }
+  asm volatile("" ::: "memory");                               // compiler: keep the request order
   const f32x4* w4 = reinterpret_cast<const f32x4*>(in_w) + lane;              // float4 column `lane` of row 0
   f32x4 wv[8][4];
 #pragma unroll
   for (int r = 0; r < 8; ++r)
 #pragma unroll
     for (int i = 0; i < 4; ++i) wv[r][i] = w4[(long)(h * D_HEAD + wid * 8 + r) * (D_MODEL / 4) + 64 * i];
+  asm volatile("" ::: "memory");
 
-  // this split's slice of the cached rows; first K/V tile in flight before the prologue (it does not depend on q)
+  // ---- x = norm1(h) of row b into LDS ----
+  if (SKP > 0) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (team) {
+      const int cc = tt * 4;
+      v = p[0];
+#pragma unroll
+      for (int ks = 1; ks < SKP; ++ks)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += p[ks][e];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += bi[e];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = rr[e] + v[e];
+      if (h_out && h == 0 && z == 0) *reinterpret_cast<f32x4*>(h_out + (long)b * D_MODEL + cc) = v;
+    }
+    const float s1 = wave_sum64((v[0] + v[1]) + (v[2] + v[3]));
+    if (team && (tt & 63) == 0) st[0][tt >> 6] = s1;
+    lds_barrier();
+    const float mean = ((st[0][0] + st[0][1]) + (st[0][2] + st[0][3])) * (1.0f / D_MODEL);
+    float q2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q2 += d * d; }
+    q2 = wave_sum64(q2);
+    if (team && (tt & 63) == 0) st[1][tt >> 6] = q2;
+    lds_barrier();
+    const float rstd = 1.0f / sqrtf(((st[1][0] + st[1][1]) + (st[1][2] + st[1][3])) * (1.0f / D_MODEL) + LN_EPS);
+    if (team) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * gg[e] + be[e];
+      *reinterpret_cast<f32x4*>(&xs[tt * 4]) = o;
+    }
+  } else if (team) {
+    *reinterpret_cast<f32x4*>(&xs[tt * 4]) = x0;
+  }
+
+  // this split's slice of the cached rows: the first K/V tile is requested here -- it does not depend on q, and the q rows' FMAs
+  // and the barrier below run under its latency
   const f32x4* kp = reinterpret_cast<const f32x4*>(kc + head_base) + c;
   const f32x4* vp = reinterpret_cast<const f32x4*>(vc + head_base) + c;
   const int chunk = ((npast + NSPL - 1) / NSPL + 15) & ~15;
@@ -1001,55 +1071,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void dec_attn_qkv_kernel(
     VV[u] = __builtin_nontemporal_load(vp + (long)t * 16);                 \
   }
   if (base < t1) { ATT_LOAD(kA, vA, base) }
-
-  // ---- x = norm1(h) of row b into LDS ----
-  if (SKP > 0) {
-    const int tt = threadIdx.x;
-    const bool team = tt < 256;                               // one 256-thread team (thread tt owns float4 column tt)
-    f32x4 v = {0.f, 0.f, 0.f, 0.f}, gg = v, be = v;
-    if (team) {
-      const int cc = tt * 4;
-      f32x4 p[SKP > 0 ? SKP : 1];
-#pragma unroll
-      for (int ks = 0; ks < SKP; ++ks) p[ks] = *reinterpret_cast<const f32x4*>(partial_in + ((long)ks * MB + b) * D_MODEL + cc);
-      gg = *reinterpret_cast<const f32x4*>(g + cc);
-      be = *reinterpret_cast<const f32x4*>(bb + cc);
-      const f32x4 rr = *reinterpret_cast<const f32x4*>(resid + (long)b * D_MODEL + cc);
-      const f32x4 bi = *reinterpret_cast<const f32x4*>(pbias + cc);
-      v = p[0];
-#pragma unroll
-      for (int ks = 1; ks < SKP; ++ks)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += p[ks][e];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += bi[e];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = rr[e] + v[e];
-      if (h_out && h == 0 && z == 0) *reinterpret_cast<f32x4*>(h_out + (long)b * D_MODEL + cc) = v;
-    }
-    const float s1 = wave_sum64((v[0] + v[1]) + (v[2] + v[3]));
-    if (team && (tt & 63) == 0) st[0][tt >> 6] = s1;
-    __syncthreads();
-    const float mean = ((st[0][0] + st[0][1]) + (st[0][2] + st[0][3])) * (1.0f / D_MODEL);
-    float q2 = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q2 += d * d; }
-    q2 = wave_sum64(q2);
-    if (team && (tt & 63) == 0) st[1][tt >> 6] = q2;
-    __syncthreads();
-    const float rstd = 1.0f / sqrtf(((st[1][0] + st[1][1]) + (st[1][2] + st[1][3])) * (1.0f / D_MODEL) + LN_EPS);
-    if (team) {
-      f32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * gg[e] + be[e];
-      *reinterpret_cast<f32x4*>(&xs[tt * 4]) = o;
-    }
-  } else if (threadIdx.x < 256) {
-    // layer 0: the sampler (or dec_embed_ln_pack) left norm1(h) in the packed image: float4 column c4 -> (c4 >> 1) * 64 + b + 32 (c4 & 1)
-    const int c4 = threadIdx.x;
-    *reinterpret_cast<f32x4*>(&xs[c4 * 4]) = *(reinterpret_cast<const f32x4*>(xp) + ((long)(c4 >> 1) * 64 + b + 32 * (c4 & 1)));
-  }
-  __syncthreads();
+  lds_barrier();
 
   // ---- q: the wave's 8 rows ----
   f32x4 xv[4];
@@ -1076,7 +1098,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void dec_attn_qkv_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i) we[r][i] = w4[(long)erow[r] * (D_MODEL / 4) + 64 * i];
   }
-  __syncthreads();
+  lds_barrier();
   const f32x4 q4 = *reinterpret_cast<const f32x4*>(&sh_q[c * 4]);                   // already scaled by 1/8
   if (z == 0 && threadIdx.x < 16) *reinterpret_cast<f32x4*>(qk_new + ((long)(b * N_HEAD + h) * 2) * D_HEAD + c * 4) = q4;
 
