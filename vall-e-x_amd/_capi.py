@@ -14,6 +14,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvallex_hip.so")
+if os.environ.get("VX_LIB"):       # kernel development only: an experiment build of the SAME sources (_build.py --variant=...), for A/B runs
+    LIB_PATH = os.path.abspath(os.environ["VX_LIB"])
 
 VX_OK, VX_EINVAL, VX_EHIP, VX_ESTATE, VX_ENOTFOUND = 0, -1, -2, -3, -4
 

@@ -685,6 +685,24 @@ void launch_dec_embed_ln_pack(const int* tok, const int* pos, const float* tab, 
 // grid = (head, row, split).  Lane = (g = lane>>4 : row slot, c = lane&15 : float4 chunk of the 64-float row).
 // ------------------------------------------------------------------------------------------------------------
 
+// Workgroup barrier that orders LDS traffic only: this wave's LDS writes are complete (lgkmcnt), then s_barrier.  __syncthreads()
+// carries a workgroup-scope fence that the compiler implements as s_waitcnt vmcnt(0): in dec_attn_qkv_kernel every barrier of the
+// LayerNorm prologue would wait for the 256 KB of weight rows requested before it.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// dec_attn_kernel's two epilogue barriers order LDS traffic only; with __syncthreads() the first one also waited for the W_o values
+// that were requested in front of the combine precisely so that their L2 latency would run under it.  -DVX_DEC_ATTN_SYNC=1 (A/B builds)
+// restores the fenced barrier.
+#if defined(VX_DEC_ATTN_SYNC)
+#define VX_DEC_ATTN_BARRIER() __syncthreads()
+#else
+#define VX_DEC_ATTN_BARRIER() lds_barrier()
+#endif
+
 constexpr int ATT_U = 4;              // rows per lane-group per buffer; two buffers in flight (2 x 8 KiB per wave)
 constexpr int ATT_WAVES = 8;          // 512-thread workgroup
 constexpr int ATT_STRIDE = ATT_WAVES * 4 * ATT_U;   // rows consumed per block iteration
@@ -869,7 +887,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
     *reinterpret_cast<f32x4*>(&sh_o[r][wid][c * 4]) = o;
     if (c == 0) { sh_m[r][wid] = m; sh_l[r][wid] = l; }
   }
-  __syncthreads();
+  VX_DEC_ATTN_BARRIER();
   if (wid == 0 && g == 0) {
     float mt = NEG_BIG;
 #pragma unroll
@@ -901,7 +919,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
   if (FUSE_OUT) {
 #pragma unroll
     for (int dg = 0; dg < 8; ++dg) wo2[dg] = wh[(8 + dg) * D_MODEL];
-    __syncthreads();
+    VX_DEC_ATTN_BARRIER();
     float acc[NR];
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) acc[rr] = 0.f;
@@ -950,15 +968,6 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
 // packed image the sampler left.  (First version, measured in profiles/r04_sb_qkv_ab.log: two extra workgroups per (head, row) for
 // k_new / v_new; the one with q AND k_new to contract set the kernel's duration, 10.8 us at one row.)
 // ------------------------------------------------------------------------------------------------------------
-// Workgroup barrier that orders LDS traffic only: this wave's LDS writes are complete (lgkmcnt), then s_barrier.  __syncthreads()
-// carries a workgroup-scope fence that the compiler implements as s_waitcnt vmcnt(0): in dec_attn_qkv_kernel every barrier of the
-// LayerNorm prologue would wait for the 256 KB of weight rows requested before it.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
 template <int SKP, int NSPL>
 __global__ __launch_bounds__(ATT_WAVES * 64, 2) void dec_attn_qkv_kernel(
     const float* __restrict__ in_w, const float* __restrict__ in_b, float* __restrict__ kc, float* __restrict__ vc, int Tmax,
@@ -973,6 +982,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void dec_attn_qkv_kernel(
   __shared__ __attribute__((aligned(16))) float sh_o[ATT_WAVES][64];
   __shared__ float sh_m[ATT_WAVES], sh_l[ATT_WAVES];
   __shared__ float st[2][4];
+  VX_STAMP(6, 0);
   const int slot = blockIdx.y;
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   const i32x4 meta = *reinterpret_cast<const i32x4*>(slot_meta + 4 * slot);
@@ -1072,6 +1082,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void dec_attn_qkv_kernel(
   }
   if (base < t1) { ATT_LOAD(kA, vA, base) }
   lds_barrier();
+  VX_STAMP(6, 1);
 
   // ---- q: the wave's 8 rows ----
   f32x4 xv[4];
@@ -1100,6 +1111,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void dec_attn_qkv_kernel(
   }
   lds_barrier();
   const f32x4 q4 = *reinterpret_cast<const f32x4*>(&sh_q[c * 4]);                   // already scaled by 1/8
+  VX_STAMP(6, 2);
   if (z == 0 && threadIdx.x < 16) *reinterpret_cast<f32x4*>(qk_new + ((long)(b * N_HEAD + h) * 2) * D_HEAD + c * 4) = q4;
 
   float m = NEG_BIG, l = 0.f;
@@ -1137,6 +1149,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void dec_attn_qkv_kernel(
   }
 #undef ATT_LOAD
 #undef ATT_CONSUME
+  VX_STAMP(6, 3);
   // ---- the share of k_new / v_new (weights long arrived) ----
   const long pn = (long)(b * N_HEAD + h) * NS1 + NSPL;                                // the new token's partial
 #pragma unroll
@@ -1197,6 +1210,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void dec_attn_qkv_kernel(
     *reinterpret_cast<f32x4*>(part_o + pi * D_HEAD + c * 4) = ot;
     if (c == 0) { part_ml[pi * 2] = mt; part_ml[pi * 2 + 1] = lt; }
   }
+  VX_STAMP(6, 4);
 }
 
 // false = configuration not instantiated (skp: slabs of the previous layer's linear2, 0 for layer 0; nsplit 4 / 8 / 16)
