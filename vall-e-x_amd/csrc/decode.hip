@@ -694,15 +694,6 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-// dec_attn_kernel's two epilogue barriers order LDS traffic only; with __syncthreads() the first one also waited for the W_o values
-// that were requested in front of the combine precisely so that their L2 latency would run under it.  -DVX_DEC_ATTN_SYNC=1 (A/B builds)
-// restores the fenced barrier.
-#if defined(VX_DEC_ATTN_SYNC)
-#define VX_DEC_ATTN_BARRIER() __syncthreads()
-#else
-#define VX_DEC_ATTN_BARRIER() lds_barrier()
-#endif
-
 constexpr int ATT_U = 4;              // rows per lane-group per buffer; two buffers in flight (2 x 8 KiB per wave)
 constexpr int ATT_WAVES = 8;          // 512-thread workgroup
 constexpr int ATT_STRIDE = ATT_WAVES * 4 * ATT_U;   // rows consumed per block iteration
@@ -887,7 +878,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
     *reinterpret_cast<f32x4*>(&sh_o[r][wid][c * 4]) = o;
     if (c == 0) { sh_m[r][wid] = m; sh_l[r][wid] = l; }
   }
-  VX_DEC_ATTN_BARRIER();
+  lds_barrier();      // LDS traffic only (measured equal to the fenced barrier, profiles/r04_dec_attn_barrier_ab.log)
   if (wid == 0 && g == 0) {
     float mt = NEG_BIG;
 #pragma unroll
@@ -919,7 +910,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
   if (FUSE_OUT) {
 #pragma unroll
     for (int dg = 0; dg < 8; ++dg) wo2[dg] = wh[(8 + dg) * D_MODEL];
-    VX_DEC_ATTN_BARRIER();
+    lds_barrier();
     float acc[NR];
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) acc[rr] = 0.f;
@@ -983,15 +974,15 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void dec_attn_qkv_kernel(
   __shared__ float sh_m[ATT_WAVES], sh_l[ATT_WAVES];
   __shared__ float st[2][4];
   VX_STAMP(6, 0);
-  const int slot = blockIdx.y;
+  // On this chain launch slot == batch row (the engine keeps the launch order of <= 4 rows in batch order), so NOTHING the prologue
+  // requests depends on the slot record: the record (context length, active flag), the LayerNorm inputs of the row and the weight
+  // rows of the head all go out at once.  (With b = meta[0] the record was one full memory round trip in front of everything:
+  // profiles/r04_timeline_b1_before.log, x in LDS 3.4 us and q ready 5.6 us after the start.)
   typedef int i32x4 __attribute__((ext_vector_type(4)));
-  const i32x4 meta = *reinterpret_cast<const i32x4*>(slot_meta + 4 * slot);
-  const int h = blockIdx.x, b = meta[0], z = blockIdx.z;
-  if (meta[2] == 0) return;                                   // row finished: uniform over the workgroup
+  const int h = blockIdx.x, b = blockIdx.y, z = blockIdx.z;
+  const i32x4 meta = *reinterpret_cast<const i32x4*>(slot_meta + 4 * b);
   constexpr int NS1 = NSPL + 1;                               // partials per (row, head): the context splits + the new token
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, gq = lane >> 4, c = lane & 15;
-  const int ctx = meta[1], npast = ctx - 1;
-  const long head_base = ((long)(b * N_HEAD + h) * Tmax) * D_HEAD;
   // Order of the requests = order of need.  A CU's vector-memory path serves its waves' requests in order (~64 B per clock): the 12
   // small loads of the LayerNorm prologue go FIRST, then the 256 KB of q rows (which the prologue's latency then hides), and the first
   // K/V tile only behind the prologue -- it is needed after q.  (With the weight rows in front, the prologue's loads waited ~2 us in
@@ -1021,6 +1012,9 @@ __global__ __launch_bounds__(ATT_WAVES * 64, 2) void dec_attn_qkv_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i) wv[r][i] = w4[(long)(h * D_HEAD + wid * 8 + r) * (D_MODEL / 4) + 64 * i];
   asm volatile("" ::: "memory");
+  if (meta[0] != b || meta[2] == 0) return;                   // row finished (or not this chain's slot order): uniform over the workgroup
+  const int ctx = meta[1], npast = ctx - 1;
+  const long head_base = ((long)(b * N_HEAD + h) * Tmax) * D_HEAD;
 
   // ---- x = norm1(h) of row b into LDS ----
   if (SKP > 0) {

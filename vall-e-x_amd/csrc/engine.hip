@@ -247,8 +247,10 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
   // order of the contexts never changes during generation (every active row grows by one per step).
   std::vector<int> by_len(nrows), st_ord(nrows);
   for (int i = 0; i < nrows; ++i) by_len[i] = i;
-  if (c->balance_rows) std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int b2) { return st_ctx[a] > st_ctx[b2]; });
-  if (!c->balance_rows) st_ord = by_len;                          // VX_BALANCE_ROWS=0: batch order
+  // (<= SB_ROWS rows: batch order -- the fused small-batch attention relies on slot == row, and there is nothing to balance)
+  const bool balance = c->balance_rows && nrows > SB_ROWS;
+  if (balance) std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int b2) { return st_ctx[a] > st_ctx[b2]; });
+  if (!balance) st_ord = by_len;                                  // batch order (also VX_BALANCE_ROWS=0)
   else {
     const int first = (nrows + 1) / 2;
     for (int y = 0; y < first; ++y) st_ord[y] = by_len[y];
