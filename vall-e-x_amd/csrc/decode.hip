@@ -697,6 +697,7 @@ __device__ __forceinline__ void lds_barrier() {
 constexpr int ATT_U = 4;              // rows per lane-group per buffer; two buffers in flight (2 x 8 KiB per wave)
 constexpr int ATT_WAVES = 8;          // 512-thread workgroup
 constexpr int ATT_STRIDE = ATT_WAVES * 4 * ATT_U;   // rows consumed per block iteration
+static_assert(ATT_STRIDE == DEC_ATTN_TILE, "the engine's Tmax guard for the fused variant");
 
 // FUSE_OUT (only launched with nsplit == 1): out_proj (modules/activation.py:166) is folded into the epilogue.  The
 // workgroup of (head h, row b) multiplies its normalised 64-float head output with the head's 64 columns of W_o and writes
@@ -710,10 +711,12 @@ constexpr int ATT_STRIDE = ATT_WAVES * 4 * ATT_U;   // rows consumed per block i
 // L2 -> CU read (64 B/clk per CU) is what the epilogue costs, is read once per two rows.
 template <bool FUSE_OUT, int SK>
 __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_attn_kernel(
-    const float* __restrict__ qkv_partial, const float* __restrict__ qkv_bias, float* __restrict__ kc,
-    float* __restrict__ vc, int Tmax, const int* __restrict__ slot_meta, float* __restrict__ xp_out,
-    float* __restrict__ part_o, float* __restrict__ part_ml, int nsplit, const float* __restrict__ wo_heads,
-    float* __restrict__ out_heads, int batch) {
+    // the first 16 dwords arrive preloaded in SGPRs (-amdgpu-kernarg-preload-count=16, _build.py): everything the requests at the
+    // head of the kernel are built from -- the K / V arena, the slot records, Tmax, batch -- sits there; an argument behind them
+    // costs an s_load round trip (the grid's y extent too: it is derived from `batch` instead of read from the dispatch packet)
+    float* __restrict__ kc, float* __restrict__ vc, const int* __restrict__ slot_meta, int Tmax, int batch, int nsplit, int,
+    const float* __restrict__ qkv_partial, const float* __restrict__ qkv_bias, float* __restrict__ xp_out,
+    float* __restrict__ part_o, float* __restrict__ part_ml, const float* __restrict__ wo_heads, float* __restrict__ out_heads) {
   constexpr int NR = FUSE_OUT ? 2 : 1;        // rows per workgroup
   __shared__ __attribute__((aligned(16))) float sh_o[NR][ATT_WAVES][64];
   __shared__ __attribute__((aligned(16))) float sh_ot[NR][64];
@@ -725,37 +728,60 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
   // in block-id order, two per CU); fused, they share a workgroup.  Either way every CU streams about the same KV bytes.
   VX_STAMP(6, 0);
   const int r = FUSE_OUT ? (int)(threadIdx.x >> 9) : 0;
-  const int slot = FUSE_OUT ? (int)blockIdx.y + r * (int)gridDim.y : (int)blockIdx.y;
+  const int gy = (batch + 1) >> 1;            // == gridDim.y of the fused launch
+  const int slot = FUSE_OUT ? (int)blockIdx.y + r * gy : (int)blockIdx.y;
   const bool valid = slot < batch;
+  const int h = blockIdx.x, sp = blockIdx.z;
+  const int lane = threadIdx.x & 63, wid = (threadIdx.x >> 6) & (ATT_WAVES - 1), g = lane >> 4, c = lane & 15;
+  // The KV arena is indexed by launch SLOT (the prefill scatters a sequence's K / V into the arena row of its slot, engine.hip):
+  // the address of this workgroup's stream follows from the block id alone.
+  const long head_base = ((long)((valid ? slot : 0) * N_HEAD + h) * Tmax) * D_HEAD;
+  const f32x4* kp = reinterpret_cast<const f32x4*>(kc + head_base) + c;
+  const f32x4* vp = reinterpret_cast<const f32x4*>(vc + head_base) + c;
+  constexpr int RS = ATT_WAVES * 4;           // row stride between a lane-group's consecutive rows
+  f32x4 kA[ATT_U], vA[ATT_U], kB[ATT_U], vB[ATT_U];
+  // One context split (the 32-row chain): the first tile -- rows 0 .. ATT_STRIDE-1 of the stream -- is requested HERE, before the
+  // slot record below has arrived: the record is a dependent memory round trip (~1.5 us: written by the previous step's sampler,
+  // it comes from memory in every launch) during which nothing streamed.  Every context of at least a tile holds real rows there.
+  // (The record is requested FIRST: loads return in order, so waiting for a record requested behind the tile would wait for the
+  // tile.)
+#if defined(VX_DEC_ATTN_LATE_TILE)             // A/B builds: the first tile behind the record, as until round 4
+  constexpr bool early = false;
+#else
+  constexpr bool early = FUSE_OUT;            // the engine only fuses when Tmax >= DEC_ATTN_TILE (weights.hip)
+#endif
   typedef int i32x4 __attribute__((ext_vector_type(4)));
-  const i32x4 meta = *reinterpret_cast<const i32x4*>(slot_meta + 4 * (valid ? slot : 0));
-  const int h = blockIdx.x, b = meta[0], sp = blockIdx.z;
+  i32x4 meta = *reinterpret_cast<const i32x4*>(slot_meta + 4 * (valid ? slot : 0));
+  __builtin_amdgcn_sched_barrier(0);
+  if (early) {
+#pragma unroll
+    for (int u = 0; u < ATT_U; ++u) kA[u] = __builtin_nontemporal_load(kp + (long)(wid * 4 + g + RS * u) * 16);
+#pragma unroll
+    for (int u = 0; u < ATT_U; ++u) vA[u] = __builtin_nontemporal_load(vp + (long)(wid * 4 + g + RS * u) * 16);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" : "+v"(meta));     // all four words stay allocated up to here: no register of the record is reused (= waited for) above
+  const int b = meta[0];
   const bool live = valid && meta[2] != 0;
   bool live_rr[NR];                                       // fused: the state of BOTH halves, the same in every thread
   if (!FUSE_OUT) {
     if (!live) return;
     live_rr[0] = true;
   } else {
-    const int s1 = (int)blockIdx.y + (int)gridDim.y;
+    const int s1 = (int)blockIdx.y + gy;
     live_rr[0] = slot_meta[4 * (int)blockIdx.y + 2] != 0;
     live_rr[NR - 1] = s1 < batch && slot_meta[4 * (s1 < batch ? s1 : 0) + 2] != 0;
     if (!live_rr[0] && !live_rr[NR - 1]) return;          // uniform over the workgroup
   }
-  const int lane = threadIdx.x & 63, wid = (threadIdx.x >> 6) & (ATT_WAVES - 1), g = lane >> 4, c = lane & 15;
   const int ctx = live ? meta[1] : 1;         // cached rows INCLUDING the new token (at ctx-1); a dead half streams nothing
   const int npast = ctx - 1;
-  const long head_base = ((long)(b * N_HEAD + h) * Tmax) * D_HEAD;
-  const f32x4* kp = reinterpret_cast<const f32x4*>(kc + head_base) + c;
-  const f32x4* vp = reinterpret_cast<const f32x4*>(vc + head_base) + c;
 
   // this block's slice of the past rows; this lane-group's rows are first, first + 16*WAVES/4.. (stride per u)
   const int chunk = ((npast + nsplit - 1) / nsplit + 15) & ~15;
   const int t0 = sp * chunk;
   const int t1 = (t0 + chunk < npast) ? t0 + chunk : npast;
-  constexpr int RS = ATT_WAVES * 4;           // row stride between a lane-group's consecutive rows
   int base = t0 + wid * 4 + g;
 
-  f32x4 kA[ATT_U], vA[ATT_U], kB[ATT_U], vB[ATT_U];
 #define ATT_LOAD(KK, VV, BASE)                                             \
   _Pragma("unroll") for (int u = 0; u < ATT_U; ++u) {                       \
     int t = (BASE) + RS * u;                                               \
@@ -767,8 +793,11 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
     t = t < t1 ? t : t1 - 1;                                               \
     VV[u] = __builtin_nontemporal_load(vp + (long)t * 16);                 \
   }
-  // first tile in flight BEFORE the q/k/v reduction below (it does not depend on q)
-  if (base < t1) { ATT_LOAD(kA, vA, base) }
+  // first tile in flight BEFORE the q/k/v reduction below (it does not depend on q).  One split: it was requested above, ahead of
+  // the record; a context shorter than a tile (rows past it may never have been written) requests it again, clamped.
+  if (early ? t1 < ATT_STRIDE : true) {
+    if (base < t1) { ATT_LOAD(kA, vA, base) }
+  }
 
   // q / k_new / v_new of this head: reduce the QKV split-K partials + bias (in_proj, modules/activation.py:144).  SK is a
   // compile-time constant so that all 3 SK + 3 loads are issued together: a runtime loop waits for every slab in turn,
@@ -933,7 +962,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) {
       if (!live_rr[rr]) continue;
-      const int br = slot_meta[4 * ((int)blockIdx.y + rr * (int)gridDim.y)];
+      const int br = slot_meta[4 * ((int)blockIdx.y + rr * gy)];
       out_heads[((long)h * MB + br) * D_MODEL + threadIdx.x] = acc[rr];
     }
   }
@@ -1231,11 +1260,11 @@ bool launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias
                      const float* wo_heads, float* out_heads, hipStream_t s) {
   if (splitk != 4) return false;           // the QKV split-K factor is compiled in
   if (wo_heads && nsplit == 1)
-    hipLaunchKernelGGL((dec_attn_kernel<true, 4>), dim3(N_HEAD, (batch + 1) / 2, 1), dim3(ATT_WAVES * 64 * 2), 0, s, qkv_partial,
-                       qkv_bias, kc, vc, Tmax, slot_meta, xp_out, part_o, part_ml, 1, wo_heads, out_heads, batch);
+    hipLaunchKernelGGL((dec_attn_kernel<true, 4>), dim3(N_HEAD, (batch + 1) / 2, 1), dim3(ATT_WAVES * 64 * 2), 0, s, kc, vc, slot_meta,
+                       Tmax, batch, 1, 0, qkv_partial, qkv_bias, xp_out, part_o, part_ml, wo_heads, out_heads);
   else
-    hipLaunchKernelGGL((dec_attn_kernel<false, 4>), dim3(N_HEAD, batch, nsplit), dim3(ATT_WAVES * 64), 0, s, qkv_partial,
-                       qkv_bias, kc, vc, Tmax, slot_meta, xp_out, part_o, part_ml, nsplit, nullptr, nullptr, batch);
+    hipLaunchKernelGGL((dec_attn_kernel<false, 4>), dim3(N_HEAD, batch, nsplit), dim3(ATT_WAVES * 64), 0, s, kc, vc, slot_meta, Tmax,
+                       batch, nsplit, 0, qkv_partial, qkv_bias, xp_out, part_o, part_ml, (const float*)nullptr, (float*)nullptr);
   return true;
 }
 

@@ -235,7 +235,7 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
   MetaBuilder mb(c);
   const long o_off = mb.add(seq_off), o_len = mb.add(seq_len), o_S = mb.add(S_), o_dt = mb.add(dst_t), o_it = mb.add(id_t),
              o_lt = mb.add(lang_t), o_pt = mb.add(pos_t), o_da = mb.add(dst_a), o_ia = mb.add(id_a), o_pa = mb.add(pos_a),
-             o_rb = mb.add(row_b), o_rt = mb.add(row_t);
+             o_rt = mb.add(row_t);
   // decode state
   std::vector<int> st_pos(nrows), st_ctx(nrows), st_zero(nrows, 0), st_one(nrows, 1), st_S(nrows);
   for (int i = 0; i < nrows; ++i) {
@@ -261,6 +261,12 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
     st_meta[4 * y] = st_ord[y]; st_meta[4 * y + 1] = st_ctx[st_ord[y]]; st_meta[4 * y + 2] = 1;
     st_slot[st_ord[y]] = y;
   }
+  // The KV arena is indexed by LAUNCH SLOT, not by batch row: dec_attn knows the address of its K / V stream from its block id
+  // alone and requests the first tile before the slot record (row, context, active) has arrived (decode.hip).  The prefill
+  // scatters every sequence's K / V into the arena row of its slot; best_of: the one prefilled row has slot 0 (equal contexts
+  // keep batch order) and beam_kv_broadcast copies arena row 0 to the arena rows 1 .. beams-1 = the other beams' slots.
+  for (int& rb : row_b) rb = st_slot[rb];
+  const long o_rb = mb.add(row_b);
   const long o_sp = mb.add(st_pos), o_sc = mb.add(st_ctx), o_z = mb.add(st_zero), o_1 = mb.add(st_one), o_sS = mb.add(st_S),
              o_meta = mb.add(st_meta), o_slot = mb.add(st_slot);
   if (int e = upload_meta(c)) return e;

@@ -182,6 +182,7 @@ void launch_dec_embed_ln_pack(const int* tok, const int* pos, const float* tab, 
                               float* h, const float* g, const float* b, float* xp, int batch, hipStream_t s);
 // one-token attention over the cache, per (b, head, split); appends the new k/v (from the QKV partials).
 // wo_heads != null and nsplit == 1: out_proj fused into the epilogue, per-head partial slabs out_heads[h][MB][1024]
+constexpr int DEC_ATTN_TILE = 128;   // rows of one dec_attn tile (8 waves x 4 lane groups x 4 rows); the fused variant needs Tmax >= this
 // slot_meta [batch][4] = {row, cached rows incl. the new token, active, -} per launch slot (kept current by dec_sample /
 // dec_force_token through slot_of[row])
 bool launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias, float* kc, float* vc, int Tmax,

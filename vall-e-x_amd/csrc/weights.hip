@@ -148,6 +148,8 @@ int vx_finalize_weights(vx_ctx* c) {
   if ((e = dev_alloc(c, &c->p_o, (size_t)std::max(SK_OUT, SK_L2) * MB * d))) return e;
   if ((e = dev_alloc(c, &c->p_oh, (size_t)N_HEAD * MB * d))) return e;
   if (const char* ev = getenv("VX_FUSE_OUT")) c->fuse_out = !(ev[0] == '0');
+  // the fused dec_attn requests the first DEC_ATTN_TILE rows of every (slot, head) stream before it knows the context length
+  if (c->Tmax < DEC_ATTN_TILE) c->fuse_out = false;
   if (const char* ev = getenv("VX_BALANCE_ROWS")) c->balance_rows = !(ev[0] == '0');
   if (const char* ev = getenv("VX_NAR_TRIM")) c->nar_trim = ev[0] == '1';
   if (const char* ev = getenv("VX_GRAPH_MULTI")) c->graph_multi = !(ev[0] == '0');
