@@ -7,7 +7,7 @@
  *   gcc -std=c99 -O2 -Wall -Wextra -Werror -pedantic -Iinclude examples/c_bench.c -Lvall-e-x_amd/csrc -lvallex_hip \
  *       -Wl,-rpath,$PWD/vall-e-x_amd/csrc -lm -o examples/c_bench.bin
  *   examples/c_bench.bin [--rows 32] [--frames 600] [--steps 3] [--warmup 1] [--layers 12] [--arith 0..3] [--check]
- *                        [--no-vocos] [--plan | --plan-fill]
+ *                        [--tp N] [--no-vocos] [--plan | --plan-fill]
  *
  * It is NOT bench.py: bench.py is the contract with the driver (JSON line with roofline / cpu_baseline, ranks, RCCL).  This
  * client runs the same workload GEOMETRY -- the (prompt frames, prompt text ids, language) of rows 0..31 are the values
@@ -246,7 +246,13 @@ typedef struct job {
   vx_batch b;
 } job;
 
+static int g_force_tp;                    /* --tp N: every row is prompted by N frames (contexts of BASELINE config 5) */
+static void row_geometry_base(int g, int* tp, int* sp, int* lang);
 static void row_geometry(int g, int* tp, int* sp, int* lang) {
+  row_geometry_base(g, tp, sp, lang);
+  if (g_force_tp > 0) *tp = g_force_tp;
+}
+static void row_geometry_base(int g, int* tp, int* sp, int* lang) {
   if (g < 32) { *tp = ROWS_TABLE[g][0]; *sp = ROWS_TABLE[g][1]; *lang = ROWS_TABLE[g][2]; return; }
   seed_for("row-geometry", (uint64_t)g);            /* rows beyond the table (other ranks' rows in bench.py): same ranges */
   *tp = 150 + (int)(next_u64() % 151);
@@ -258,7 +264,7 @@ static int make_job(job* j, int first, int n) {
   memset(j, 0, sizeof *j);
   j->n = n;
   j->text_stride = 80 + N_TEXT;
-  j->prompt_stride = 300;
+  j->prompt_stride = g_force_tp > 300 ? g_force_tp : 300;
   j->text = (int32_t*)calloc((size_t)n * j->text_stride, sizeof(int32_t));
   j->lang = (int32_t*)calloc((size_t)n * j->text_stride, sizeof(int32_t));
   j->text_lens = (int32_t*)calloc((size_t)n, sizeof(int32_t));
@@ -291,7 +297,7 @@ int main(int argc, char** argv) {
   for (int i = 1; i < argc; ++i) {
 #define INTARG(flag, var) if (!strcmp(argv[i], flag) && i + 1 < argc) { var = atoi(argv[++i]); continue; }
     INTARG("--rows", rows) INTARG("--frames", frames) INTARG("--steps", steps) INTARG("--warmup", warmup)
-    INTARG("--layers", layers) INTARG("--arith", arith)
+    INTARG("--layers", layers) INTARG("--arith", arith) INTARG("--tp", g_force_tp)
 #undef INTARG
     if (!strcmp(argv[i], "--check")) { check = 1; continue; }
     if (!strcmp(argv[i], "--no-vocos")) { with_vocos = 0; continue; }
@@ -300,7 +306,8 @@ int main(int argc, char** argv) {
     fprintf(stderr, "unknown argument %s\n", argv[i]);
     return 1;
   }
-  if (rows < 1 || rows > 32 || frames < 1 || frames > 4000 || layers < 1 || layers > 12 || steps < 1 || warmup < 0) {
+  if (rows < 1 || rows > 32 || frames < 1 || frames > 4000 || layers < 1 || layers > 12 || steps < 1 || warmup < 0 ||
+      g_force_tp < 0 || g_force_tp > 2000) {
     fprintf(stderr, "need 1 <= rows <= 32, 1 <= frames <= 4000, 1 <= layers <= 12, steps >= 1, warmup >= 0\n");
     return 1;
   }
@@ -347,7 +354,7 @@ int main(int argc, char** argv) {
   vx_config cfg;
   memset(&cfg, 0, sizeof cfg);
   cfg.struct_size = (uint32_t)sizeof cfg;
-  cfg.num_layers = layers; cfg.max_batch = rows; cfg.max_text = 256; cfg.max_prompt = 320;
+  cfg.num_layers = layers; cfg.max_batch = rows; cfg.max_text = 256; cfg.max_prompt = g_force_tp > 320 ? g_force_tp : 320;
   cfg.max_new = (frames > 64 ? frames : 64) + 8;                   /* bench.build_model's geometry */
   cfg.use_graph = 1; cfg.with_vocos = with_vocos; cfg.arith = arith;
   double t0 = now_s();
@@ -461,14 +468,17 @@ int main(int argc, char** argv) {
   }
 
   const double audio_s = (double)frames_total / 75.0;
+  char tp_txt[32];
+  if (g_force_tp > 0) snprintf(tp_txt, sizeof tp_txt, "%d", g_force_tp);
+  else snprintf(tp_txt, sizeof tp_txt, "\"150..300 (bench.make_rows)\"");
   printf("{\"client\": \"examples/c_bench.c (C99 over include/vallex_hip.h, no Python)\", \"metric\": \"audio-seconds/sec\", "
          "\"value\": %.3f, \"unit\": \"audio-seconds/s\", \"steps\": %d, \"warmup\": %d, \"ms_per_step\": %.2f, "
          "\"ar_ms_per_step\": %.2f, \"nar_ms_per_step\": %.2f, \"vocos_ms_per_step\": %.2f, \"ar_tokens_per_s\": %.1f, "
-         "\"rows\": %d, \"frames\": %d, \"layers\": %d, \"gemm_mode\": %d, \"attn_mode\": %d, \"phases_rerun_in_f32\": %lld, "
+         "\"rows\": %d, \"frames\": %d, \"prompt_frames\": %s, \"layers\": %d, \"gemm_mode\": %d, \"attn_mode\": %d, \"phases_rerun_in_f32\": %lld, "
          "\"rows_truncated\": %d, \"ids_fnv1a\": \"%016llx\", \"check\": %s, \"data\": \"synthetic (SplitMix64 weights of the "
          "checkpoint's shapes; geometry of bench.make_rows rows 0..%d)\"}\n",
          audio_s / elapsed, steps, warmup, 1e3 * elapsed / steps, ar_ms / steps, nar_ms / steps, 1e3 * voc_s / steps,
-         ar_ms > 0 ? (double)frames_total / (ar_ms * 1e-3) : 0.0, rows, frames, layers, (int)gm, (int)am, (long long)fb_life,
+         ar_ms > 0 ? (double)frames_total / (ar_ms * 1e-3) : 0.0, rows, frames, tp_txt, layers, (int)gm, (int)am, (long long)fb_life,
          (int)cut, (unsigned long long)digest, check ? (failures ? "\"failed\"" : "\"ok\"") : "null", rows - 1);
   free_job(&jb);
   free(codes); free(codes2); free(lens); free(lens2); free(audio);
