@@ -2,7 +2,8 @@
  * vx_load_tensor (the 374 reference state-dict keys + the Vocos head's), BASELINE.json's batch-32 x 8 s workload through
  * vx_infer (AR prefill + cached decode + 7 NAR stages, models/vallex.py:458-686) and vx_vocos_decode
  * (utils/generation.py:148-150).  No Python, no torch, no HIP headers: what a cgo / JNI / N-API binding of the boundary
- * would do, and a harness that starts in seconds on a fresh GPU box (bench.py pays ~1-2 minutes of `import torch` there).
+ * would do, and a harness whose complete run (weights in, warm-up, three timed batches) takes 3 s on a GPU box: bench.py needed 6 s
+ * of wall time for the same on a warm box and up to 1-2 minutes of `import torch` on a box that has not paged the image in yet.
  *
  *   gcc -std=c99 -O2 -Wall -Wextra -Werror -pedantic -Iinclude examples/c_bench.c -Lvall-e-x_amd/csrc -lvallex_hip \
  *       -Wl,-rpath,$PWD/vall-e-x_amd/csrc -lm -o examples/c_bench.bin
