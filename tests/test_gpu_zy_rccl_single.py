@@ -1,7 +1,8 @@
 """GPU: the N > 1 code path of bench.py on the one GPU a box has -- `--rccl-single` takes every collective call of the multi-GPU
 path (RCCL process group bound to the device, barriers, MAX / SUM all_reduce on device tensors, all_gather_object of the per-rank
 records, vallex_amd.sharding.gather_rows of the results) with a world of ONE rank.  Not a scaling point (BASELINE config 4 needs 8
-GPUs); it keeps the branch the driver's 1/2/4/8 run depends on from being code that has never executed on hardware."""
+GPUs); it keeps the branch the driver's 1/2/4/8 run depends on from being code that has never executed on hardware.  (File name: runs
+near the end of the suite, so that a box-level RCCL problem cannot hide the parity tests behind `-x`.)"""
 import json
 import os
 import subprocess
