@@ -1,7 +1,13 @@
-"""CPU (cross-compiles, no GPU): properties of the generated gfx950 code that the design counts on and that a source edit can lose
-silently.  dec_attn (the dominant kernel, 7 200 launches per batch) must reach its first memory requests without a dependent round
-trip: every operand of those requests lies in the 16 preloaded kernarg dwords (vall-e-x_amd/_build.py), the slot record is
-requested first and the first K / V tile right behind it, and the first wait lets the tile stay in flight."""
+"""CPU (cross-compiles, no GPU): properties of the generated gfx950 code that the design counts on and that a source edit or a
+compiler update can lose silently.
+  * dec_attn (the dominant kernel, 7 200 launches per batch) reaches its first memory requests without a dependent round trip: every
+    operand of those requests lies in the 16 preloaded kernarg dwords (vall-e-x_amd/_build.py), the slot record is requested first and
+    the first K / V tile right behind it, and the first wait lets the tile stay in flight;
+  * the decode GEMMs request a whole round of x and (non-temporal) weight blocks before their first MFMA -- the step is a chain of memory
+    round trips, a load sunk to its use is one more of them;
+  * the steady-state loop of the 256 x 256 f16x2 GEMM is what section 5 describes per pair of K tiles: 2 rendezvous, 2 x 48 MFMAs
+    (3 per 32 x 32 x 16 block), 2 x 24 fragment reads, 2 x 8 LDS-DMA requests spread between the MFMAs, nothing spilled;
+  * the tile loop of the f16x2 attention: per pair of key tiles 2 barriers, 2 x 24 MFMAs, 2 x 16 fragment reads, one v_exp per score."""
 import importlib.util
 import os
 import re
@@ -20,16 +26,29 @@ def _product_flags(src):
     return m._hipcc(), m.FLAGS + m.EXTRA_FLAGS.get(src, [])
 
 
-def test_fused_dec_attn_reaches_its_first_requests_without_a_round_trip(tmp_path):
-    hipcc, flags = _product_flags("decode.hip")
-    if shutil.which(hipcc) is None and not os.path.exists(hipcc):
-        pytest.skip("no hipcc")
-    out = tmp_path / "decode.s"
-    r = subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", "-o", str(out),
-                                          os.path.join(ROOT, "vall-e-x_amd", "csrc", "decode.hip")], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = out.read_text().splitlines()
-    start = next(i for i, ln in enumerate(lines) if re.match(r"_ZN2vx15dec_attn_kernelILb1ELi4EEE\w*:", ln))
+_ASM = {}
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    """source name -> lines of the device assembly the PRODUCT flags give it (compiled once per module)"""
+    def get(src):
+        if src not in _ASM:
+            hipcc, flags = _product_flags(src)
+            if shutil.which(hipcc) is None and not os.path.exists(hipcc):
+                pytest.skip("no hipcc")
+            out = tmp_path_factory.mktemp("isa") / (src + ".s")
+            r = subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", "-o", str(out),
+                                                  os.path.join(ROOT, "vall-e-x_amd", "csrc", src)], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-2000:]
+            _ASM[src] = out.read_text().splitlines()
+        return _ASM[src]
+    return get
+
+
+def kernel_body(lines, symbol_re):
+    """instructions and labels of one kernel (comments and directives stripped)"""
+    start = next(i for i, ln in enumerate(lines) if re.match(symbol_re + r"\w*:", ln))
     body = []
     for ln in lines[start + 1:]:
         if ln.startswith("\ts_endpgm") or ln.startswith(".Lfunc_end"):
@@ -37,6 +56,43 @@ def test_fused_dec_attn_reaches_its_first_requests_without_a_round_trip(tmp_path
         ln = ln.split(";")[0].rstrip()
         if ln.strip():
             body.append(ln.strip())
+    return body
+
+
+def loops(body):
+    """every [label .. backward branch to it] span of a kernel body"""
+    pos = {ln[:-1]: i for i, ln in enumerate(body) if ln.endswith(":")}
+    out = []
+    for i, ln in enumerate(body):
+        m = re.match(r"s_c?branch\w*\s+(\.\w+)", ln)
+        if m and pos.get(m.group(1), i) < i:
+            out.append(body[pos[m.group(1)]: i + 1])
+    return out
+
+
+def count(seq, pattern):
+    return sum(1 for ln in seq if re.match(pattern, ln))
+
+
+def metadata(lines, name_substr, key):
+    """a field of the kernel's record in the amdhsa.kernels metadata (the compiler's own figure); a record starts at `  - .` and its
+    keys are sorted, so some of them precede `.name`"""
+    at = next(i for i, ln in enumerate(lines) if ".name:" in ln and name_substr in ln)
+    lo = at
+    while not lines[lo].lstrip().startswith("- ."):
+        lo -= 1
+    hi = at + 1
+    while hi < len(lines) and not lines[hi].lstrip().startswith("- .") and not lines[hi].startswith("amdhsa."):
+        hi += 1
+    for ln in lines[lo:hi]:
+        t = ln.strip().lstrip("- ")
+        if t.startswith("." + key + ":"):
+            return int(t.split(":")[1])
+    raise KeyError((name_substr, key))
+
+
+def test_fused_dec_attn_reaches_its_first_requests_without_a_round_trip(asm):
+    body = kernel_body(asm("decode.hip"), r"_ZN2vx15dec_attn_kernelILb1ELi4EEE")
     # with kernarg preload the hardware enters 256 bytes behind the symbol: skip the compatibility header (s_load ... s_branch)
     entry = next(i for i, ln in enumerate(body) if ln.startswith("s_branch")) + 1
     head = body[entry:]
@@ -46,3 +102,53 @@ def test_fused_dec_attn_reaches_its_first_requests_without_a_round_trip(tmp_path
     loads = [ln for ln in before if ln.startswith("global_load_dwordx4")]
     assert len(loads) == 9 and " nt" not in loads[0] and all(" nt" in ln for ln in loads[1:]), loads     # record, then 4 K + 4 V rows
     assert re.search(r"vmcnt\(8\)", head[first_wait]), head[first_wait]                                   # waits for the record only
+
+
+def test_decode_gemms_request_a_whole_round_before_their_first_mfma(asm):
+    lines = asm("decode.hip")
+    for sym, name, n_loads, n_nt in ((r"_ZN2vx18skinny_gemm_kernelE", "skinny_gemm_kernel", 16, 8),             # 8 x blocks + 8 weight blocks
+                                     (r"_ZN2vx25skinny16_relu_pack_kernelE", "skinny16_relu_pack_kernel", 8, 4)):
+        body = kernel_body(lines, sym)
+        first_mfma = next(i for i, ln in enumerate(body) if ln.startswith("v_mfma"))
+        loads = [ln for ln in body[:first_mfma] if ln.startswith("global_load_dwordx4")]
+        assert len(loads) >= n_loads, (name, len(loads))
+        assert sum(" nt" in ln for ln in loads) >= n_nt, (name, "the weight stream must be non-temporal")
+        assert metadata(lines, name, "private_segment_fixed_size") == 0, name
+    # the streaming loop of dec_attn keeps a tile of each of K and V in flight per iteration, all of it non-temporal
+    stream = max(loops(kernel_body(lines, r"_ZN2vx15dec_attn_kernelILb1ELi4EEE")), key=len)
+    ld = [ln for ln in stream if ln.startswith("global_load_dwordx4")]
+    assert len(ld) == 16 and all(" nt" in ln for ln in ld), ld
+    assert count(stream, r"s_barrier") == 0 and count(stream, r"ds_") == 0          # q . k through DPP row sums: no LDS, no barrier
+
+
+def test_f16x2_gemm_steady_state_loop(asm):
+    lines = asm("gemm_f16x2.hip")
+    body = kernel_body(lines, r"_ZN2vx17gemm_f16x2_kernelILi256ELi256ELi2ELi0EEE")
+    main = max(loops(body), key=lambda lp: count(lp, r"v_mfma"))
+    # one iteration = two K tiles of 32 (the two LDS stages trade places)
+    assert count(main, r"v_mfma_f32_32x32x16_f16") == 96          # 8 blocks x 3 products x 2 k16 steps x 2 tiles per wave
+    assert count(main, r"s_barrier") == 2                          # ONE rendezvous per K tile
+    assert count(main, r"ds_read_b128") == 48                      # (2 + 4) operand blocks x 2 planes x 2 k16 steps x 2 tiles
+    assert count(main, r"global_load_lds_dwordx4") == 16           # 8 KiB per wave and stage, one request behind every sixth MFMA
+    assert count(main, r"scratch_|buffer_store|buffer_load") == 0
+    # the requests are spread: never two LDS-DMA instructions without an MFMA between them
+    kinds = [("d" if ln.startswith("global_load_lds") else "m") for ln in main if ln.startswith(("global_load_lds", "v_mfma"))]
+    assert "dd" not in "".join(kinds)
+    assert metadata(lines, "gemm_f16x2_kernelILi256ELi256ELi2ELi0E", "private_segment_fixed_size") == 0
+    assert metadata(lines, "gemm_f16x2_kernelILi256ELi256ELi2ELi0E", "vgpr_count") <= 256          # two waves per SIMD
+    assert metadata(lines, "gemm_f16x2_kernelILi256ELi256ELi2ELi0E", "group_segment_fixed_size") == 131072
+
+
+def test_f16x2_attention_tile_loop(asm):
+    lines = asm("attn_full_h2.hip")
+    body = kernel_body(lines, r"_ZN2vx19attn_full_h2_kernelILi0EEE")
+    main = max(loops(body), key=lambda lp: count(lp, r"v_mfma"))
+    # one iteration = two key tiles of 32 (score registers and LDS buffers alternate roles)
+    assert count(main, r"v_mfma_f32_32x32x16_f16") == 48          # per tile: 12 for S^T (one chain) + 12 for O^T (two chains)
+    assert count(main, r"s_barrier") == 2                          # one barrier per tile
+    assert count(main, r"ds_read_b128") == 32                      # per tile: 4 k-steps x 2 K planes + 2 k-steps x 2 halves x 2 V planes
+    assert count(main, r"v_exp_f32") == 34                         # 16 scores per lane and tile + the rescale of the running maximum
+    assert count(main, r"global_load_dwordx4") == 8                # the staged K / V rows of tile t + 3 (two of each per thread)
+    assert count(main, r"scratch_") == 0
+    assert metadata(lines, "attn_full_h2_kernelILi0E", "private_segment_fixed_size") == 0
+    assert metadata(lines, "attn_full_h2_kernelILi0E", "vgpr_count") <= 256                          # two 4-wave workgroups per CU = two waves per SIMD
