@@ -32,7 +32,7 @@ typedef struct vx_ctx vx_ctx;
 /* ABI guard.  Every descriptor struct starts with `struct_size` = sizeof(that struct) as the CALLER compiled it; the library
  * rejects a mismatch with VX_EINVAL instead of reading past the end of a shorter (older) struct.  vx_abi_version() returns
  * VX_ABI_VERSION of the library that was actually loaded, so a binding can check it before the first call. */
-#define VX_ABI_VERSION 4
+#define VX_ABI_VERSION 5
 int32_t vx_abi_version(void);
 
 /* Model/arena geometry.  d_model=1024, 16 heads, FFN 4096, 8 codebooks are fixed by the kernels
@@ -168,6 +168,15 @@ int vx_last_truncated(vx_ctx* ctx, int32_t* rows);
  * automatically; the call succeeds with the fp32 result.  This reports how many phases of the last vx_infer / vx_ar_prefill /
  * vx_nar took that path, and the count since vx_create (any pointer may be NULL). */
 int vx_last_fallbacks(vx_ctx* ctx, int32_t* prefill_phases, int32_t* nar_phases, int64_t* lifetime_phases);
+
+/* Sticky fallback (ABI 5).  After two CONSECUTIVE raises of a phase kind (a clean f16x2 pass of the kind resets the count) the
+ * context runs that kind on the exact-fp32 kernels directly instead of paying an f16x2 pass and an fp32 pass per call; every 32nd
+ * phase of the kind is tried on f16x2 again and a clean pass leaves sticky mode.  vx_fallback_state reports whether the AR prefill /
+ * the NAR stages are in sticky mode right now and how many times the context entered it since vx_create (any pointer may be NULL);
+ * vx_fallback_reset leaves it at once (e.g. after a batch of known outlier inputs).  No reference counterpart: the reference is
+ * fp32 throughout. */
+int vx_fallback_state(vx_ctx* ctx, int32_t* sticky_prefill, int32_t* sticky_nar, int64_t* times_engaged);
+int vx_fallback_reset(vx_ctx* ctx);
 
 /* the arithmetic the context actually runs (after vx_finalize_weights): gemm_mode / attn_mode = 0 f16x2, 1 bf16x3, 2 fp32 */
 int vx_arith_mode(vx_ctx* ctx, int32_t* gemm_mode, int32_t* attn_mode);

@@ -243,6 +243,10 @@ def test_long_text_without_prompt_accepts_any_mode_like_the_reference(monkeypatc
     assert len(fm.calls) == 4
 
 
+class _NotOnTheAllowList:
+    """a picklable class the weights-only unpickler does not know (stands for anything a hostile checkpoint could carry)"""
+
+
 def test_preload_models_reads_the_checkpoint_file_like_the_reference(tmp_path, monkeypatch):
     """utils/generation.py:50-89 with no arguments: ./checkpoints/vallex-checkpoint.pt -> torch.load(...)["model"] ->
     load_state_dict(strict=True).  Goes through the FILE (torch.save of {"model": state_dict, ...} as the published checkpoint
@@ -291,13 +295,28 @@ def test_preload_models_reads_the_checkpoint_file_like_the_reference(tmp_path, m
     assert got["strict"] is True and sorted(got["keys"]) == sorted(expected_keys(12)) and got["dtypes"] == {"torch.float32"}
     assert got["ctor"][0][:3] == (1024, 16, 12)
     assert G.model is not None and G.vocos is None                       # no Vocos file given: generate_audio would refuse
-    # a checkpoint with a pickled non-tensor object next to "model" (training state): weights_only refuses it, the loader
-    # falls back to the permissive load the reference's torch 2.0 did
+    # a checkpoint with the trainer's bookkeeping next to "model" (argparse.Namespace, a path): allow-listed, still weights-only
     import argparse
-    torch.save({"model": full, "args": argparse.Namespace(lr=1e-4)}, tmp_path / "checkpoints" / "vallex-checkpoint.pt")
+    import pathlib
+    torch.save({"model": full, "args": argparse.Namespace(lr=1e-4), "exp_dir": pathlib.PosixPath("exp/valle")},
+               tmp_path / "checkpoints" / "vallex-checkpoint.pt")
     got.clear()
     G.preload_models()
     assert len(got["keys"]) == 374
+    # any OTHER pickled class is refused (the permissive unpickler runs code from the file) unless the caller opts in
+    torch.save({"model": full, "sampler": _NotOnTheAllowList()}, tmp_path / "checkpoints" / "vallex-checkpoint.pt")
+    got.clear()
+    monkeypatch.delenv("VALLEX_ALLOW_UNSAFE_PICKLE", raising=False)
+    with pytest.raises(RuntimeError, match="allow_unsafe_pickle"):
+        G.preload_models()
+    assert not got
+    G.preload_models(allow_unsafe_pickle=True)
+    assert len(got["keys"]) == 374
+    got.clear()
+    monkeypatch.setenv("VALLEX_ALLOW_UNSAFE_PICKLE", "1")
+    G.preload_models()
+    assert len(got["keys"]) == 374
+    monkeypatch.delenv("VALLEX_ALLOW_UNSAFE_PICKLE")
     # the real VALLE mirror accepts the file's dict strictly (and rejects one with a missing key)
     from vallex_amd.models.vallex import VALLE as RealVALLE
     m = RealVALLE(1024, 16, 12, norm_first=True, add_prenet=False, prefix_mode=1, share_embedding=True, nar_scale_factor=1.0,

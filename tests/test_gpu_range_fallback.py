@@ -147,3 +147,66 @@ def test_a_model_that_keeps_leaving_the_range_goes_straight_to_fp32():
         assert (fb["prefill"], fb["nar"]) == (1, 1), (call, fb)
         assert fb["lifetime"] == life + 2 * (call + 1), (call, fb)
         assert_codes(f"nl2_range_ffn call {call}", out, golden(base))
+
+
+def test_sticky_mode_is_reported_warned_about_and_can_be_left():
+    """ABI 5 (vx_fallback_state / vx_fallback_reset): the context says when it is in sticky mode, Engine.infer warns at the moment
+    the mode engages (not only at the first raise), a reset leaves it at once, and the consecutive-raise count starts again"""
+    import warnings
+    base, kind = RANGE_CASES["nl2_range_ffn"]
+    c = ALL["nl2_range_ffn"]
+    row, us = inputs_row(c)
+    m = case_model(c)
+    e = m.engine
+    e.fallback_reset()
+    st = e.fallback_state()
+    assert (st["prefill"], st["nar"]) == (False, False), st
+    t0 = st["times_engaged"]
+    e._fb_warned, e._sticky_seen = False, t0
+    u = None if us is None else us[:, None]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = _run(m, c, [row], u)[0]                       # first raise of each kind: re-run, not sticky yet
+        assert_codes("sticky call 0", out, golden(base))
+        st = e.fallback_state()
+        assert (st["prefill"], st["nar"], st["times_engaged"]) == (False, False, t0), st
+        assert any("left the fp16 range" in str(x.message) for x in w) and not any("ENGAGED" in str(x.message) for x in w)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = _run(m, c, [row], u)[0]                       # second CONSECUTIVE raise of each kind: both kinds go sticky
+        assert_codes("sticky call 1", out, golden(base))
+        st = e.fallback_state()
+        assert (st["prefill"], st["nar"], st["times_engaged"]) == (True, True, t0 + 2), st
+        assert any("ENGAGED" in str(x.message) for x in w), [str(x.message) for x in w]
+    e.fallback_reset()
+    st = e.fallback_state()
+    assert (st["prefill"], st["nar"], st["times_engaged"]) == (False, False, t0 + 2), st
+    out = _run(m, c, [row], u)[0]                           # after the reset one raise is not enough again
+    assert_codes("sticky call 2", out, golden(base))
+    assert e.fallback_state()["prefill"] is False and e.last_fallbacks()["prefill"] == 1
+
+
+def test_a_clean_phase_resets_the_consecutive_count():
+    """two raises that are NOT consecutive (a clean pass of the kind between them) never engage sticky mode: the AR-only
+    rescaled model raises in the prefill and runs clean NAR phases, so its NAR count stays 0 and only the prefill goes sticky;
+    an in-range model never moves either count"""
+    from oracle import synth
+    from tests import _util
+    base, kind = RANGE_CASES["nl2_range_ffn"]
+    c = ALL[base]
+    row, us = inputs_row(c)
+    u = None if us is None else us[:, None]
+    sd = synth.vallex_state_dict(c["num_layers"], c["seed"], c["eos_gain"])
+    m = _util.VALLE(1024, 16, c["num_layers"], norm_first=True, add_prenet=False, prefix_mode=1, share_embedding=True,
+                    nar_scale_factor=1.0, prepend_bos=True, num_quantizers=8, engine_max_new=320, engine_max_prompt=400,
+                    engine_max_text=256, engine_max_batch=4)
+    m.to("cuda:0").load_state_dict(synth.out_of_range_state_dict(sd, c["num_layers"], kind, stacks=("ar",)), strict=True)
+    for call in range(3):
+        assert_codes(f"ar-only call {call}", _run(m, c, [row], u)[0], golden(base))
+        st = m.engine.fallback_state()
+        assert st["nar"] is False and st["prefill"] is (call >= 1), (call, st)
+    m2 = case_model(c)                                      # the in-range base model
+    for call in range(3):
+        assert_codes(f"in-range call {call}", _run(m2, c, [row], u)[0], golden(base))
+    assert m2.engine.fallback_state() == dict(prefill=False, nar=False, times_engaged=0)
+    assert m2.engine.last_fallbacks()["lifetime"] == 0

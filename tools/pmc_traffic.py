@@ -26,6 +26,9 @@ KERNELS = {  # json suffix -> (kernel-name substring, what the algorithmic bytes
     "skinny16": "skinny16_relu_pack_kernel",
     "attn_full_x3": "attn_full_x3_kernel",
     "attn_full_h2": "attn_full_h2_kernel",
+    "gemm_f32": "gemm_f32_kernel",          # the reference-arithmetic leg (bench.py --arith f32): every projection
+    "attn_full": "attn_full_kernel",        # and the exact-fp32 full-sequence attention
+    "gemm_bf16x3": "gemm_bf16x3_dma_kernel",
 }
 
 
@@ -41,17 +44,24 @@ def algo_dec_attn():
     return tot + 1024 * 1024 * 4
 
 
-def main(csv_path, rnd):
+def main(csv_path, rnd, arith=""):
+    """arith: the --arith the profiled bench command ran with ("" = the product default); it is part of the `source` string and
+    keeps a Vocos-only gemm_f32 average of a default-arithmetic pass from being mistaken for the fp32 leg's."""
     import bench
     rows = list(csv.DictReader(open(csv_path)))
     for key, sub in KERNELS.items():
+        if key in ("gemm_f32", "attn_full") and arith != "f32":
+            continue
+        if key == "gemm_bf16x3" and arith != "bf16x3":
+            continue
         sel = [r for r in rows if sub in r["kernel"] and r["counter"] == "FETCH_SIZE"]
         if not sel:
             continue
         n = sum(int(r["dispatches"]) for r in sel)
         avg_kb = sum(float(r["avg"]) * int(r["dispatches"]) for r in sel) / n
         out = {"kernel": sub, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python bench.py --steps 1 --warmup 0 "
-                                        "--no-cpu-baseline --no-profile (tools/pmc_traffic.py)",
+                                        "--no-cpu-baseline --no-profile --no-ref-arith" + (f" --arith {arith}" if arith else "")
+                                        + " (tools/pmc_traffic.py)",
                "launches": n, "avg_FETCH_SIZE_KB": round(avg_kb, 1),
                "correction": "x2: gfx950 FETCH_SIZE tallies the 128-B requests of wide (16 B/lane) streaming reads at 64 B "
                              "(MI355X_MICROARCH.md, HBM)",
@@ -67,4 +77,4 @@ def main(csv_path, rnd):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "02")
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "02", sys.argv[3] if len(sys.argv) > 3 else "")

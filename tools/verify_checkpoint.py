@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--frames", type=int, default=150)
     ap.add_argument("--ariths", default="f16x2,f32")
     ap.add_argument("--no-gpu", action="store_true")
+    ap.add_argument("--allow-unsafe-pickle", action="store_true",
+                    help="load files the weights-only unpickler refuses with weights_only=False (executes code from the file: trusted origin only)")
     ap.add_argument("--out")
     args = ap.parse_args()
 
@@ -97,7 +99,7 @@ def main():
     ok = True
     # ---- load ----------------------------------------------------------------------------------------------------------
     t0 = time.time()
-    ck = G._torch_load(args.ckpt)
+    ck = G._torch_load(args.ckpt, args.allow_unsafe_pickle or None)
     sd_t = ck["model"]
     nl = count_layers(sd_t)
     m = VALLE(1024, 16, nl, norm_first=True, add_prenet=False, prefix_mode=1, share_embedding=True, nar_scale_factor=1.0,
@@ -153,7 +155,7 @@ def main():
                 ok &= res[j["name"]]["equal"]
             rep["parity"]["oracle_vs_reference (no GPU)"] = res
     else:
-        vsd = G._torch_load(args.vocos) if args.vocos else None
+        vsd = G._torch_load(args.vocos, args.allow_unsafe_pickle or None) if args.vocos else None
         for arith in args.ariths.split(","):
             m.engine_opts["arith"] = arith
             m._engine = None

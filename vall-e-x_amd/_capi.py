@@ -14,8 +14,17 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvallex_hip.so")
-if os.environ.get("VX_LIB"):       # kernel development only: an experiment build of the SAME sources (_build.py --variant=...), for A/B runs
-    LIB_PATH = os.path.abspath(os.environ["VX_LIB"])
+LIB_OVERRIDDEN = False
+if os.environ.get("VX_LIB"):
+    # kernel development only: an experiment build of the SAME sources (_build.py --variant=...) for A/B runs.  Honoured only together
+    # with VX_DEV=1, announced on stderr, and the library's ABI version is checked before any other symbol is bound (load_library).
+    if os.environ.get("VX_DEV") == "1":
+        LIB_PATH = os.path.abspath(os.environ["VX_LIB"])
+        LIB_OVERRIDDEN = True
+    else:
+        import warnings
+        warnings.warn("VX_LIB is set but VX_DEV=1 is not: ignoring it and loading the in-tree library (VX_LIB is a kernel-development "
+                      "hook, not a deployment option)", RuntimeWarning)
 
 VX_OK, VX_EINVAL, VX_EHIP, VX_ESTATE, VX_ENOTFOUND = 0, -1, -2, -3, -4
 
@@ -48,11 +57,12 @@ class vx_sampling(C.Structure):
 
 
 # every symbol include/vallex_hip.h declares (tests/test_abi.py checks the library exports exactly these)
-ABI_VERSION = 4       # VX_ABI_VERSION of include/vallex_hip.h this binding was written against
+ABI_VERSION = 5       # VX_ABI_VERSION of include/vallex_hip.h this binding was written against
 
 SYMBOLS = ["vx_abi_version", "vx_create", "vx_destroy", "vx_last_error", "vx_synchronize", "vx_load_tensor", "vx_finalize_weights",
            "vx_infer", "vx_vocos_decode", "vx_encodec_decode", "vx_encodec_encode", "vx_ar_prefill", "vx_ar_logits", "vx_ar_step",
-           "vx_nar", "vx_read_tap", "vx_last_stats", "vx_last_truncated", "vx_last_fallbacks", "vx_arith_mode"]
+           "vx_nar", "vx_read_tap", "vx_last_stats", "vx_last_truncated", "vx_last_fallbacks", "vx_fallback_state",
+           "vx_fallback_reset", "vx_arith_mode"]
 # ... and include/vallex_hip_dev.h: measurement / kernel development, never called by the mirrors of the reference API
 DEV_SYMBOLS = ["vx_prof_enable", "vx_prof_get", "vx_prof_reset", "vx_bench_kernel", "vx_bench_gemm", "vx_bench_attn",
                "vx_bench_gemm_clock"]
@@ -69,6 +79,9 @@ def load_library() -> C.CDLL:
         raise OSError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
     lib = C.CDLL(LIB_PATH)
+    if LIB_OVERRIDDEN:
+        import sys
+        print(f"[vallex_amd] VX_DEV=1 VX_LIB: loading the experiment library {LIB_PATH} instead of the in-tree build", file=sys.stderr)
     lib.vx_abi_version.argtypes = []
     lib.vx_abi_version.restype = C.c_int32
     if lib.vx_abi_version() != ABI_VERSION:
@@ -106,6 +119,8 @@ def load_library() -> C.CDLL:
     lib.vx_last_stats.argtypes = [ctx, P(C.c_int64), P(C.c_int64), P(C.c_double), P(C.c_double)]
     lib.vx_last_truncated.argtypes = [ctx, P(C.c_int32)]
     lib.vx_last_fallbacks.argtypes = [ctx, P(C.c_int32), P(C.c_int32), P(C.c_int64)]
+    lib.vx_fallback_state.argtypes = [ctx, P(C.c_int32), P(C.c_int32), P(C.c_int64)]
+    lib.vx_fallback_reset.argtypes = [ctx]
     lib.vx_arith_mode.argtypes = [ctx, P(C.c_int32), P(C.c_int32)]
     for name in SYMBOLS + DEV_SYMBOLS:
         fn = getattr(lib, name)
@@ -237,18 +252,26 @@ class Engine:
         return [out[i, : lens[i]].copy() for i in range(batch.n)]
 
     def _warn_fallbacks(self):
-        """one warning per engine when the f16x2 range guard re-ran a phase in fp32 (vx_last_fallbacks): results are the
-        reference's either way, but a model that does this on every call runs ~3x slower than with arith='f32' chosen up front"""
-        if getattr(self, "_fb_warned", False):
-            return
+        """Warnings when the f16x2 range guard re-ran a phase in fp32 (vx_last_fallbacks): once per engine at the first raise, and
+        again EVERY time the context enters sticky mode (vx_fallback_state: the affected phase kind now runs on the ~3x slower
+        fp32 kernels directly until a probe pass comes back clean).  Results are the reference's either way."""
+        import warnings
         fb = self.last_fallbacks()
-        if fb["lifetime"]:
-            import warnings
+        if fb["lifetime"] and not getattr(self, "_fb_warned", False):
             self._fb_warned = True
             warnings.warn(f"activations of this model left the fp16 range of the f16x2 kernels: {fb['prefill']} prefill / {fb['nar']} NAR "
-                          "phase(s) of this call were re-run on the exact-fp32 kernels (results are exact; after two such calls the "
-                          "engine goes to fp32 directly).  If this model does it regularly, create the engine with arith='f32'.",
+                          "phase(s) of this call were re-run on the exact-fp32 kernels (results are exact; after two consecutive such "
+                          "phases the engine goes to fp32 directly).  If this model does it regularly, create the engine with arith='f32'.",
                           RuntimeWarning, stacklevel=3)
+        if fb["lifetime"]:
+            st = self.fallback_state()
+            if st["times_engaged"] > getattr(self, "_sticky_seen", 0):
+                self._sticky_seen = st["times_engaged"]
+                kinds = [k for k in ("prefill", "nar") if st[k]]
+                warnings.warn(f"sticky fp32 fallback ENGAGED for {' + '.join(kinds) or 'a phase kind'}: two consecutive phases left the fp16 "
+                              "range, so this kind now runs on the exact-fp32 kernels directly (~3x slower on these phases); every 32nd "
+                              "phase is tried on f16x2 again and a clean pass leaves the mode, Engine.fallback_reset() leaves it at once",
+                              RuntimeWarning, stacklevel=3)
 
     def vocos_decode(self, codes: Sequence[np.ndarray], bandwidth_id: int = 2):
         n = len(codes)
@@ -361,6 +384,16 @@ class Engine:
         p, n, t = C.c_int32(), C.c_int32(), C.c_int64()
         self._chk(self.lib.vx_last_fallbacks(self.ctx, C.byref(p), C.byref(n), C.byref(t)))
         return dict(prefill=p.value, nar=n.value, lifetime=t.value)
+
+    def fallback_state(self):
+        """sticky fp32 fallback: is the AR prefill / the NAR phase in sticky mode right now, and how often the context entered it"""
+        p, n, t = C.c_int32(), C.c_int32(), C.c_int64()
+        self._chk(self.lib.vx_fallback_state(self.ctx, C.byref(p), C.byref(n), C.byref(t)))
+        return dict(prefill=bool(p.value), nar=bool(n.value), times_engaged=t.value)
+
+    def fallback_reset(self):
+        """leave sticky mode and forget the consecutive-raise counts (e.g. after a batch of known outlier inputs)"""
+        self._chk(self.lib.vx_fallback_reset(self.ctx))
 
     def arith_mode(self):
         """(gemm, attention) arithmetic of the full-sequence path: 'f16x2' | 'bf16x3' | 'f32' each"""

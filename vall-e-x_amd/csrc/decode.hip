@@ -145,6 +145,70 @@ void launch_skinny_gemm(const float* Wp, const float* xp, float* partial, int Np
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// EXPERIMENT (VX_QKV_BALANCED=1): the in_proj GEMM of the decode step on a grid that divides the chip.  skinny_gemm_kernel runs it as
+// 96 column tiles x 4 K slices = 384 workgroups on 256 CUs: half the CUs stream two 32 KB tiles, the other half one, and the launch
+// ends with the loaded half (profiles/r02_step_timeline.log: average workgroup done at 3.7 us, last at 5.3 us; linear2 with its 256
+// workgroups 4.8 / 5.6).  Here the 32 column tiles of q are cut into EIGHT K slices (256 workgroups x 16 KB) and the 64 tiles of k, v
+// stay at four (256 workgroups x 32 KB): 512 workgroups, dispatched in block-id order two per CU, one of each kind = 48 KB on every CU.
+// k and v: the arithmetic of skinny_gemm_kernel with splitk = 4, operation for operation (same slabs).  q: eight slabs instead of four
+// (a different summation order: dec_attn_kernel<*, 84> sums them, and the goldens decide).  Slab layout unchanged,
+// out[(ks * MB + b) * 3072 + n]; the k / v columns of slabs 4..7 are never written or read.
+__global__ __launch_bounds__(256, 2) void skinny_qkv_bal_kernel(const float* __restrict__ Wp, const float* __restrict__ xp,
+                                                             float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
+  constexpr int Npad = 3 * D_MODEL, KB = D_MODEL / 8;
+  const int id = blockIdx.x;
+  const bool isq = id < 256;                                       // uniform over the workgroup
+  const int nt = isq ? (id & 31) : 32 + ((id - 256) & 63);
+  const int ks = isq ? (id >> 5) : ((id - 256) >> 6);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int kb0 = (ks * 4 + wid) * (isq ? 4 : 8);                  // k-blocks of 8 per wave: 4 (q, 8 slices) or 8 (k / v, 4 slices)
+  const f32x4* wp = reinterpret_cast<const f32x4*>(Wp) + ((long)nt * KB + kb0) * 64 + lane;
+  const f32x4* xq = reinterpret_cast<const f32x4*>(xp) + (long)kb0 * 64 + lane;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  f32x4 w[8], x[8];
+  if (isq) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = xq[(long)u * 64];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w[u] = __builtin_nontemporal_load(wp + (long)u * 64);
+    __builtin_amdgcn_sched_barrier(0);      // every request before the first MFMA (left alone the scheduler sinks the loads to their uses)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[u][j], x[u][j], acc, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = xq[(long)u * 64];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w[u] = __builtin_nontemporal_load(wp + (long)u * 64);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[u][j], x[u][j], acc, 0, 0, 0);
+  }
+  // the four waves' partial sums, combined exactly as in skinny_gemm_kernel (ascending wave order)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[((wid * 16 + r) * 64) + lane] = acc[r];
+  __syncthreads();
+  f32x4 t;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float* rp = red + ((wid * 4 + j) * 64) + lane;
+    t[j] = ((rp[0] + rp[16 * 64]) + rp[2 * 16 * 64]) + rp[3 * 16 * 64];
+  }
+  float* dst = out + ((long)ks * MB + (lane & 31)) * Npad + nt * 32 + 4 * (lane >> 5);
+  *reinterpret_cast<f32x4*>(dst + wid * 8) = t;
+}
+
+void launch_skinny_qkv_balanced(const float* Wp, const float* xp, float* partial, hipStream_t s) {
+  hipLaunchKernelGGL(skinny_qkv_bal_kernel, dim3(512), dim3(256), 0, s, Wp, xp, partial);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // linear1 (N = 4096) with its epilogue fused and NO split-K: 16-row weight tiles on v_mfma_f32_16x16x4_f32 give
 // 256 workgroups (one per CU), 8 waves each splitting K; the 32 batch rows are two 16-wide MFMA column blocks that
 // share one weight fragment.  out = relu(x.W^T + bias) is written straight into linear2's packed-x image
@@ -804,25 +868,33 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
   // SK + 1 dependent memory round trips at the head of the launch with only the first K/V tile in flight.
   f32x4 q4, k4, v4;
   {
+    // SK > 10 (experiment, skinny_qkv_bal_kernel): SK / 10 slabs of q, SK % 10 slabs of k and v
+    constexpr int SKQ = SK > 10 ? SK / 10 : SK, SKV = SK > 10 ? SK % 10 : SK;
     const int NP = 3 * D_MODEL;
     const float* p = qkv_partial + (long)b * NP + h * D_HEAD + c * 4;
-    f32x4 pq[SK], pk[SK], pv[SK];
+    f32x4 pq[SKQ], pk[SKV], pv[SKV];
 #pragma unroll
-    for (int ks = 0; ks < SK; ++ks) {
+    for (int ks = 0; ks < SKV; ++ks) {                 // (the product's request order for SK <= 10)
       const float* ps = p + (long)ks * MB * NP;
       pq[ks] = *reinterpret_cast<const f32x4*>(ps);
       pk[ks] = *reinterpret_cast<const f32x4*>(ps + D_MODEL);
       pv[ks] = *reinterpret_cast<const f32x4*>(ps + 2 * D_MODEL);
     }
+#pragma unroll
+    for (int ks = SKV; ks < SKQ; ++ks) pq[ks] = *reinterpret_cast<const f32x4*>(p + (long)ks * MB * NP);
     const float* bp = qkv_bias + h * D_HEAD + c * 4;
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp);
     const f32x4 b1 = *reinterpret_cast<const f32x4*>(bp + D_MODEL);
     const f32x4 b2 = *reinterpret_cast<const f32x4*>(bp + 2 * D_MODEL);
     q4 = pq[0]; k4 = pk[0]; v4 = pv[0];
 #pragma unroll
-    for (int ks = 1; ks < SK; ++ks)
+    for (int ks = 1; ks < SKV; ++ks)
 #pragma unroll
       for (int e = 0; e < 4; ++e) { q4[e] += pq[ks][e]; k4[e] += pk[ks][e]; v4[e] += pv[ks][e]; }
+#pragma unroll
+    for (int ks = SKV; ks < SKQ; ++ks)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q4[e] += pq[ks][e];
 #pragma unroll
     for (int e = 0; e < 4; ++e) { q4[e] = (q4[e] + b0[e]) * 0.125f; k4[e] += b1[e]; v4[e] += b2[e]; }
   }
@@ -1258,6 +1330,15 @@ bool launch_dec_attn_qkv(const float* in_w, const float* in_b, float* kc, float*
 bool launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias, float* kc, float* vc, int Tmax,
                      const int* slot_meta, float* xp_out, float* part_o, float* part_ml, int nsplit, int batch,
                      const float* wo_heads, float* out_heads, hipStream_t s) {
+  if (splitk == 84) {                      // experiment: 8 slabs of q, 4 of k / v (skinny_qkv_bal_kernel)
+    if (wo_heads && nsplit == 1)
+      hipLaunchKernelGGL((dec_attn_kernel<true, 84>), dim3(N_HEAD, (batch + 1) / 2, 1), dim3(ATT_WAVES * 64 * 2), 0, s, kc, vc, slot_meta,
+                         Tmax, batch, 1, 0, qkv_partial, qkv_bias, xp_out, part_o, part_ml, wo_heads, out_heads);
+    else
+      hipLaunchKernelGGL((dec_attn_kernel<false, 84>), dim3(N_HEAD, batch, nsplit), dim3(ATT_WAVES * 64), 0, s, kc, vc, slot_meta, Tmax,
+                         batch, nsplit, 0, qkv_partial, qkv_bias, xp_out, part_o, part_ml, (const float*)nullptr, (float*)nullptr);
+    return true;
+  }
   if (splitk != 4) return false;           // the QKV split-K factor is compiled in
   if (wo_heads && nsplit == 1)
     hipLaunchKernelGGL((dec_attn_kernel<true, 4>), dim3(N_HEAD, (batch + 1) / 2, 1), dim3(ATT_WAVES * 64 * 2), 0, s, kc, vc, slot_meta,

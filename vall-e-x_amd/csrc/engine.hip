@@ -295,7 +295,11 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
       // and every workgroup of a head re-reads the head's q slice through L2 -- few splits win (profiles/r04_sb_qkv_ab.log)
       const int fit[5] = {0, 8, 8, 4, 4};
       const int ns2 = c->sb_qkv_nsplit > 0 ? c->sb_qkv_nsplit : fit[nrows];
-      if (sb_qkv_chain_supported(SK_L2, SK_OUT, ns2, nrows)) { c->nsplit = ns2; c->sb_qkv = true; }
+      // dec_attn_qkv_kernel addresses the KV arena and its partials by batch ROW and returns when slot_meta[slot].row != row
+      // (decode.hip): it is only selected while the launch order is the identity -- checked here, not assumed from `balance` above
+      bool identity = true;
+      for (int y = 0; y < nrows; ++y) identity = identity && st_ord[y] == y;
+      if (identity && sb_qkv_chain_supported(SK_L2, SK_OUT, ns2, nrows)) { c->nsplit = ns2; c->sb_qkv = true; }
     }
   }
 
@@ -426,11 +430,15 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
   }
   for (int l = 0; l < NL; ++l) {
     const LayerW& L = c->ar[l];
-    { ProfScope ps(c, 1); launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, st); }
+    {
+      ProfScope ps(c, 1);
+      if (c->qkv_bal) launch_skinny_qkv_balanced(L.in_wp, c->xp, c->p_qkv, st);
+      else launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, st);
+    }
     const bool fused = c->fuse_out && c->nsplit == 1;
     {
       ProfScope ps(c, 0);
-      LAUNCH(launch_dec_attn(c->p_qkv, SK_QKV, L.in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax, c->slot_meta,
+      LAUNCH(launch_dec_attn(c->p_qkv, c->qkv_bal ? 84 : SK_QKV, L.in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax, c->slot_meta,
                       c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, fused ? L.out_wh : nullptr, c->p_oh, st));
     }
     if (fused) {
@@ -493,12 +501,26 @@ int ar_step_run(vx_ctx* c, const SampleArgs* sa, const std::string& sig, int nst
   return VX_OK;
 }
 
+// ---- sticky fp32 fallback bookkeeping (engine_ctx.h) -----------------------------------------------------------
+// does this phase go to the fp32 kernels directly?  In sticky mode yes, except every FB_STICKY_PROBE_EVERY-th phase (a probe on f16x2)
+static bool fb_direct(vx_ctx* c, bool sticky, int& age) {
+  if (!sticky || !range_guarded(c)) return false;
+  if (++age >= FB_STICKY_PROBE_EVERY) { age = 0; return false; }
+  return true;
+}
+// outcome of a phase that RAN on f16x2: a raise counts towards sticky mode, a clean pass resets the count and leaves sticky mode
+static void fb_outcome(vx_ctx* c, bool raised, int& raises, bool& sticky, int& age) {
+  if (!range_guarded(c)) return;
+  if (!raised) { raises = 0; sticky = false; age = 0; return; }
+  if (++raises >= FB_STICKY_AFTER && !sticky) { sticky = true; age = 0; ++c->sticky_engaged; }
+}
+
 // ---- AR generation for one micro-batch -----------------------------------------------------------------------
 int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int nb, std::vector<int>& n_gen,
                 std::vector<int>& gen, int beams = 1) {
   const int nb_rows = nb;                            // rows of the caller's batch that this micro-batch prefills
   // a context whose prefills keep leaving the fp16 range runs them on the exact-fp32 kernels straight away (sticky fallback)
-  const bool direct_f32 = c->sticky_prefill_f32 && range_guarded(c);
+  const bool direct_f32 = fb_direct(c, c->sticky_prefill_f32, c->sticky_prefill_age);
   if (direct_f32) {
     ++c->st_fb_prefill; ++c->fb_total;
     if (int e = ensure_f32_buffers(c)) return e;
@@ -540,12 +562,12 @@ int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int 
     return VX_OK;
   };
   if (int e = first_sample()) return e;
+  if (!direct_f32) fb_outcome(c, raised, c->fb_prefill_raises, c->sticky_prefill_f32, c->sticky_prefill_age);
   if (raised) {
     // an operand of the prefill left the fp16 range: the K/V cache, the residual row and the logits are not to be trusted.
     // Re-run the prefill on the exact-fp32 kernels (it resets the decode state) and sample the first token again.
     HIPCHK(hipMemsetAsync(c->range_flag, 0, sizeof(int), c->stream));
     ++c->st_fb_prefill; ++c->fb_total;
-    if (++c->fb_prefill_raises >= FB_STICKY_AFTER) c->sticky_prefill_f32 = true;
     if (int e = ensure_f32_buffers(c)) return e;
     {
       F32Scope f32(c);
@@ -716,11 +738,11 @@ int nar_generate_once(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::v
 int nar_generate(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::vector<int>& T, const int* codes0,
                  long codes0_stride, std::vector<int>& out_codes /* [7][sumT] */, long& sumT_out) {
   int e = VX_RETRY_F32;
-  const bool direct_f32 = c->sticky_nar_f32 && range_guarded(c);          // sticky fallback (engine_ctx.h)
+  const bool direct_f32 = fb_direct(c, c->sticky_nar_f32, c->sticky_nar_age);          // sticky fallback (engine_ctx.h)
   if (!direct_f32) {
     e = nar_generate_once(c, b, r0, nb, T, codes0, codes0_stride, out_codes, sumT_out);
+    if (e == VX_OK || e == VX_RETRY_F32) fb_outcome(c, e == VX_RETRY_F32, c->fb_nar_raises, c->sticky_nar_f32, c->sticky_nar_age);
     if (e != VX_RETRY_F32) return e;
-    if (++c->fb_nar_raises >= FB_STICKY_AFTER) c->sticky_nar_f32 = true;
   }
   // an operand of one of the 7 stages left the fp16 range: the whole phase (again) on the exact-fp32 kernels (F32Scope)
   ++c->st_fb_nar; ++c->fb_total;
@@ -810,11 +832,11 @@ int vx_ar_prefill(vx_ctx* c, const vx_batch* b) {
   HIPCHK(hipSetDevice(c->dev));
   if (int e = check_batch(c, b, c->mbr)) return e;
   c->st_fb_prefill = c->st_fb_nar = 0;
-  bool raised = c->sticky_prefill_f32 && range_guarded(c);
+  bool raised = fb_direct(c, c->sticky_prefill_f32, c->sticky_prefill_age);
   if (!raised) {
     if (int e = ar_prefill(c, b, 0, b->batch)) return e;
     if (int e = take_range_flag(c, &raised)) return e;       // syncs when the mode is guarded
-    if (raised && ++c->fb_prefill_raises >= FB_STICKY_AFTER) c->sticky_prefill_f32 = true;
+    fb_outcome(c, raised, c->fb_prefill_raises, c->sticky_prefill_f32, c->sticky_prefill_age);
   }
   if (raised) {
     ++c->st_fb_prefill; ++c->fb_total;
@@ -978,6 +1000,22 @@ int vx_last_fallbacks(vx_ctx* c, int32_t* prefill_phases, int32_t* nar_phases, i
   if (prefill_phases) *prefill_phases = c->st_fb_prefill;
   if (nar_phases) *nar_phases = c->st_fb_nar;
   if (lifetime) *lifetime = c->fb_total;
+  return VX_OK;
+}
+
+int vx_fallback_state(vx_ctx* c, int32_t* sticky_prefill, int32_t* sticky_nar, int64_t* times_engaged) {
+  if (!c) return VX_EINVAL;
+  if (sticky_prefill) *sticky_prefill = c->sticky_prefill_f32;
+  if (sticky_nar) *sticky_nar = c->sticky_nar_f32;
+  if (times_engaged) *times_engaged = c->sticky_engaged;
+  return VX_OK;
+}
+
+int vx_fallback_reset(vx_ctx* c) {
+  if (!c) return VX_EINVAL;
+  c->fb_prefill_raises = c->fb_nar_raises = 0;
+  c->sticky_prefill_f32 = c->sticky_nar_f32 = false;
+  c->sticky_prefill_age = c->sticky_nar_age = 0;
   return VX_OK;
 }
 

@@ -43,6 +43,7 @@ struct ProfClass {
 constexpr int SK_QKV = 4, SK_OUT = 4, SK_L2 = 8, SK_PRED = 4;
 constexpr int PRED_NPAD = 1056;
 constexpr int FB_STICKY_AFTER = 2;
+constexpr int FB_STICKY_PROBE_EVERY = 32;
 
 }  // namespace vxe
 using namespace vxe;
@@ -85,10 +86,16 @@ struct vx_ctx {
   int st_fb_prefill = 0, st_fb_nar = 0;     // phases of the last call that were re-run in fp32 (vx_last_fallbacks)
   long fb_total = 0;                        // ... since the context was created
   // sticky fallback: a checkpoint whose operands leave the fp16 range on (nearly) every call would pay an f16x2 pass AND an fp32
-  // pass each time.  After FB_STICKY_AFTER raises of a phase kind that kind runs on the exact-fp32 kernels directly (still counted
-  // by vx_last_fallbacks); after the first raise the NAR phase polls the flag right behind stage 0 instead of behind stage 6.
+  // pass each time.  After FB_STICKY_AFTER CONSECUTIVE raises of a phase kind (a clean f16x2 pass of that kind resets the count: two
+  // outlier inputs days apart in a long-running server never add up) that kind runs on the exact-fp32 kernels directly (still
+  // counted by vx_last_fallbacks); while the count is non-zero the NAR phase polls the flag right behind stage 0 instead of behind
+  // stage 6.  Sticky mode is not for ever: every FB_STICKY_PROBE_EVERY-th phase of the kind is tried on f16x2 again and a clean pass
+  // leaves it (a burst of outlier inputs costs at most that many fp32 phases).  vx_fallback_state reports it, vx_fallback_reset
+  // clears it.
   int fb_prefill_raises = 0, fb_nar_raises = 0;
   bool sticky_prefill_f32 = false, sticky_nar_f32 = false;
+  int sticky_prefill_age = 0, sticky_nar_age = 0;     // fp32-direct phases since sticky mode engaged / since the last probe
+  long sticky_engaged = 0;                            // how many times either kind ENTERED sticky mode since vx_create
   unsigned short* fa3b = nullptr;  // second plane buffer: linear1 writes linear2's A planes straight from its epilogue (f16x2 mode)
   unsigned short* fa3 = nullptr;   // activation planes [2 or 3][M][K<=4096]
   unsigned short* pred_w3[N_Q - 1] = {};
@@ -106,6 +113,7 @@ struct vx_ctx {
   int sb_qkv_rows = 4, sb_qkv_nsplit = 0;   // sb_qkv up to this many rows (VX_SB_QKV=n, 0 = off), forced split count (VX_SB_QKV_NSPLIT)
   bool sb_chain = false;           // the current micro-batch decodes on the small-batch chain (set by ar_prefill)
   bool sb_fuse = true;             // <= SB_ROWS rows: reduce+LN / combine folded into the consuming GEMM (VX_SB_FUSE=0: the general chain)
+  bool qkv_bal = false;            // experiment VX_QKV_BALANCED=1: the decode in_proj GEMM on 512 workgroups (8 K slices of q, 4 of k / v)
   float* qk_new = nullptr;         // [MB][16][2][64]: q / 8 and k_new of the step's new token (dec_attn_qkv_kernel -> out_proj prologue)
   float *p_qkv = nullptr, *p_o = nullptr, *p_oh = nullptr, *p_logits = nullptr, *part_o = nullptr, *part_ml = nullptr;
   std::map<const unsigned short*, int> w_shift;   // f16x2: power-of-two scale exponent of every weight's planes

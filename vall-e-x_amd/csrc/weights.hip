@@ -136,15 +136,21 @@ int vx_finalize_weights(vx_ctx* c) {
   c->imeta_cap = std::max(M * 24, (long)c->cfg.max_batch * c->cfg.max_new * 12) + 65536;
   if ((e = dev_alloc(c, &c->imeta, (size_t)c->imeta_cap))) return e;
   const size_t cache = (size_t)NL * c->mbr * N_HEAD * c->Tmax * D_HEAD;
-  if ((e = dev_alloc(c, &c->kc, cache, false))) return e;
-  if ((e = dev_alloc(c, &c->vc, cache, false))) return e;
+  // zero-initialised once: the fused dec_attn requests rows 0 .. DEC_ATTN_TILE - 1 of a (slot, head) stream before it knows the
+  // context length (decode.hip) and, for a slot past the batch, the stream of slot 0 -- the values are discarded (the tile is
+  // requested again, clamped, when the context is shorter), but they must be DEFINED memory: no tool flags an uninitialised read
+  // and no stale NaN pattern of a previous owner of the pages can ever meet an arithmetic instruction.  Needs Tmax >= DEC_ATTN_TILE
+  // (guard below; decode.hip static_asserts the tile size against it).
+  if ((e = dev_alloc(c, &c->kc, cache, true))) return e;
+  if ((e = dev_alloc(c, &c->vc, cache, true))) return e;
   if ((e = dev_alloc(c, &c->dh, (size_t)MB * d))) return e;
   if ((e = dev_alloc(c, &c->dh2, (size_t)MB * d))) return e;
   if (const char* ev = getenv("VX_SB_FUSE")) c->sb_fuse = !(ev[0] == '0');
   if ((e = dev_alloc(c, &c->xp, (size_t)MB * d))) return e;
   if ((e = dev_alloc(c, &c->xp_att, (size_t)MB * d))) return e;
   if ((e = dev_alloc(c, &c->xp4, (size_t)2 * MB * f))) return e;   // linear1's two split-K slabs, packed image
-  if ((e = dev_alloc(c, &c->p_qkv, (size_t)SK_QKV * MB * 3 * d))) return e;
+  if (const char* ev = getenv("VX_QKV_BALANCED")) c->qkv_bal = ev[0] == '1';
+  if ((e = dev_alloc(c, &c->p_qkv, (size_t)std::max(SK_QKV, 8) * MB * 3 * d))) return e;
   if ((e = dev_alloc(c, &c->p_o, (size_t)std::max(SK_OUT, SK_L2) * MB * d))) return e;
   if ((e = dev_alloc(c, &c->p_oh, (size_t)N_HEAD * MB * d))) return e;
   if (const char* ev = getenv("VX_FUSE_OUT")) c->fuse_out = !(ev[0] == '0');

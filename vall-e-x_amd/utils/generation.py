@@ -65,37 +65,56 @@ class VocosHIP:
         return torch.from_numpy(out) if torch is not None and isinstance(out, np.ndarray) else out
 
 
-def _torch_load(path):
-    """torch.load(path, map_location='cpu') as the reference does (utils/generation.py:79).  torch >= 2.6 defaults to
-    weights_only=True, which is what a checkpoint of plain tensors needs; the published vallex-checkpoint.pt may carry pickled
-    training state next to "model" -- then (and only then) the permissive loader is used, like the reference's torch 2.0 did."""
+def _torch_load(path, allow_unsafe_pickle: Optional[bool] = None):
+    """torch.load(path, map_location='cpu') as the reference does (utils/generation.py:79), under torch >= 2.6's
+    weights_only=True: a checkpoint of plain tensors -- what `["model"]` is -- needs nothing else.  Published training
+    checkpoints carry harmless bookkeeping objects next to "model"; the ones known from the reference's trainer
+    (argparse.Namespace, pathlib paths, OrderedDict) are allow-listed for this one load.  Anything else is REFUSED: the
+    permissive unpickler executes code from the file, so it runs only on an explicit opt-in --
+    `allow_unsafe_pickle=True` (preload_models(..., allow_unsafe_pickle=True)) or VALLEX_ALLOW_UNSAFE_PICKLE=1 -- for a
+    file whose origin the caller trusts, like the reference's torch 2.0 `torch.load` did for every file."""
+    import argparse
+    import collections
+    import pathlib
+    if allow_unsafe_pickle is None:
+        allow_unsafe_pickle = os.environ.get("VALLEX_ALLOW_UNSAFE_PICKLE", "") == "1"
+    if allow_unsafe_pickle:
+        logging.warning(f"{path}: loading with weights_only=False (explicit opt-in): the file can execute arbitrary code")
+        return torch.load(path, map_location="cpu", weights_only=False)
+    safe = [argparse.Namespace, collections.OrderedDict, pathlib.PosixPath, pathlib.PurePosixPath, pathlib.Path]
     try:
-        return torch.load(path, map_location="cpu")
+        with torch.serialization.safe_globals(safe):
+            return torch.load(path, map_location="cpu", weights_only=True)
     except Exception as e:                                   # pickle.UnpicklingError: weights-only refused a global
         if "weights_only" not in str(e) and "Weights only" not in str(e):
             raise
-        logging.warning(f"{path}: not loadable with weights_only=True ({type(e).__name__}); loading it like torch 2.0 did")
-        return torch.load(path, map_location="cpu", weights_only=False)
+        raise RuntimeError(
+            f"{path}: torch refused to load it with weights_only=True ({type(e).__name__}: it pickles objects outside the "
+            f"allow-list). Loading such a file executes code from it. If you trust its origin, pass allow_unsafe_pickle=True "
+            f"(preload_models / tools/verify_checkpoint.py --allow-unsafe-pickle) or set VALLEX_ALLOW_UNSAFE_PICKLE=1.") from e
 
 
 def preload_models(checkpoint: Optional[str] = None, vocos_checkpoint: Optional[str] = None, state_dict=None,
-                   vocos_state_dict=None, num_layers: int = NUM_LAYERS, **engine_opts):
+                   vocos_state_dict=None, num_layers: int = NUM_LAYERS, allow_unsafe_pickle: Optional[bool] = None,
+                   **engine_opts):
     """Build the engine and load weights.  With no arguments behaves like the reference (expects
-    ./checkpoints/vallex-checkpoint.pt; there is no network here, so a missing file raises instead of downloading)."""
+    ./checkpoints/vallex-checkpoint.pt; there is no network here, so a missing file raises instead of downloading).
+    Checkpoint files are read with torch's weights-only unpickler; allow_unsafe_pickle=True is the explicit opt-in to the
+    permissive one (see _torch_load)."""
     global model, vocos
     if state_dict is None:
         path = checkpoint or os.path.join(checkpoints_dir, model_checkpoint_name)
         if not os.path.exists(path):
             raise FileNotFoundError(f"{path} not found (the reference downloads it, utils/generation.py:53-65; "
                                     "no network here): pass checkpoint= or state_dict=")
-        state_dict = _torch_load(path)["model"]                                   # :79-83
+        state_dict = _torch_load(path, allow_unsafe_pickle)["model"]                                  # :79-83
     m = VALLE(N_DIM, NUM_HEAD, num_layers, norm_first=True, add_prenet=False, prefix_mode=PREFIX_MODE,
               share_embedding=True, nar_scale_factor=1.0, prepend_bos=True, num_quantizers=NUM_QUANTIZERS,
               **{"engine_" + k: v for k, v in engine_opts.items()})
     m.to(device).load_state_dict(state_dict, strict=True)
     m.eval()
     if vocos_state_dict is None and vocos_checkpoint is not None:
-        vocos_state_dict = _torch_load(vocos_checkpoint)
+        vocos_state_dict = _torch_load(vocos_checkpoint, allow_unsafe_pickle)
     if vocos_state_dict is not None:
         m.load_vocos_state_dict(vocos_state_dict)
     model = m
