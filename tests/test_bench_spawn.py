@@ -103,3 +103,33 @@ def test_bench_refuses_ranks_without_a_gpu_each():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == ""
     assert "one rank per GPU is required" in r.stderr and "--allow-shared-gpu" in r.stderr
+
+
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_bench_config_4_is_one_256_row_job_whatever_n_is(gpus):
+    """`bench.py --config 4` (BASELINE config 4): ONE job of 256 rows.  N = 1: eight sequential 32-row shards in one process, put back
+    together by sharding.gather_rows over the loopback world; N = 2: two ranks x 128 rows (four engine calls each) gathered over gloo.
+    Either way 256 rows arrive and every shard's ids digest is the same before and after the gather.  Stub engine, no GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "4", "--gpus", str(gpus), "--steps", "1", "--warmup", "0",
+                        "--frames", "6", "--stub"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _json_line(r.stdout)
+    assert j["scaling"] == "strong" and j["config"]["rows_total"] == 256 and j["config"]["rows_per_gpu"] == 256 // gpus
+    assert j["config"]["baseline_config"] == 4 and j["rows_gathered"] == 256
+    sc = j["shard_check"]
+    assert sc["match"] is True and sc["rows_gathered"] == 256 and sc["shards"] == (8 if gpus == 1 else gpus)
+    assert len(set(sc["shard_digests_before_gather"])) == sc["shards"]          # shards really hold different rows
+    assert abs(j["value"] * j["ms_per_step"] / 1e3 - 256 * 6 / 75.0) < 1e-2 * 256 * 6 / 75.0
+
+
+def test_config_4_job_digest_does_not_depend_on_the_sharding():
+    """the 256-row job gives the same ids digest on 1 rank (8 loopback shards) and on 2 ranks (gloo): row g is seeded by its GLOBAL index"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    dig = []
+    for gpus in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "4", "--gpus", str(gpus), "--steps", "1", "--warmup",
+                            "0", "--frames", "3", "--stub"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        dig.append(_json_line(r.stdout)["shard_check"]["ids_digest_job"])
+    assert dig[0] == dig[1]

@@ -49,3 +49,34 @@ def test_committed_counter_files_carry_a_stamp():
     for f in new:
         pj = json.load(open(os.path.join(prof, f)))
         assert len(pj.get("source_sha256", "")) == 64 and pj["traffic_bytes_per_launch"] > 0, f
+
+
+def test_config_3_rows_follow_the_reference_presets():
+    """BASELINE config 3: 32 rows cycling the reference's 41 preset shapes -- prompts of 161-758 frames, zh / ja / en prompt languages
+    from the .npz lang_code (macros.py:15-19), text language cycling en / zh / ja, 100 text ids after the prompt's own"""
+    import numpy as np
+    from oracle.make_golden import CODE2LANG, PRESET_SHAPES
+    rows = bench.make_preset_rows(0, 32)
+    assert len(rows) == 32
+    for g, r in enumerate(rows):
+        name, tp, sp, code = PRESET_SHAPES[g]
+        assert r["prompt"].shape == (tp, 8) and r["enroll"] == sp and len(r["text"]) == sp + 100
+        assert r["prompt_language"] == CODE2LANG[code] and r["text_language"] == ("en", "zh", "ja")[g % 3]
+        assert 0 <= r["prompt"].min() and r["prompt"].max() < 1024
+    tps = [r["prompt"].shape[0] for r in rows]
+    assert min(tps) == 161 and max(tps) == 758 and {r["prompt_language"] for r in rows} == {"zh", "ja", "en"}
+    assert max(len(r["text"]) for r in rows) == 260                     # alan: 160 prompt ids + 100 (the engine is built with max_text 320)
+    again = bench.make_preset_rows(8, 4)                                # seeded by the GLOBAL row index: any sharding sees the same job
+    assert all(np.array_equal(a["text"], b["text"]) and np.array_equal(a["prompt"], b["prompt"]) for a, b in zip(again, rows[8:12]))
+
+
+def test_loopback_world_reassembles_a_job_like_ranks_would():
+    import numpy as np
+    from vallex_amd.sharding import gather_rows, shard_range
+    job = [np.full((3, 8), g, np.int64) for g in range(37)]               # ragged: 37 rows over 8 shards
+    shards = [shard_range(37, 8, v) for v in range(8)]
+    parts = [(a, job[a:b]) for a, b in shards]
+    for a, mine in parts:
+        got = gather_rows(a, mine, 37, bench.LoopbackWorld(parts))
+        assert bench.ids_digest(got) == bench.ids_digest(job)
+    assert bench.ids_digest(job[:5]) != bench.ids_digest(job[1:6]) and len(bench.ids_digest(job)) == 16

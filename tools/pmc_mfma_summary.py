@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""MFMA / VALU busy fractions of the matrix kernels from the three rocprofv3 --pmc passes of tools/pmc_mfma.sh
+"""MFMA / VALU busy fractions of the matrix kernels from the three rocprofv3 --pmc passes of tools/gpu_call.sh mfma
 (gpurun_out/pm_{1,2,3}.csv) -> JSON on stdout (kept as profiles/rNN_mfma_busy.json).
 
 Units (MI355X_MICROARCH.md, rocprofv3 PMC section): SQ_VALU_MFMA_BUSY_CYCLES counts shader cycles, summed over all SIMDs (exactly
@@ -23,7 +23,7 @@ def main(paths):
         for r in csv.DictReader(open(p)):
             rows.setdefault(r["kernel"], {})[r["counter"]] = (float(r["avg"]), float(r["avg_dispatch_us"]), int(r["dispatches"]))
     out = {"source": "three separate `rocprofv3 --kernel-trace --pmc ...` passes of `python bench.py --steps 1 --warmup 0 --no-cpu-baseline "
-                     "--no-profile` (tools/pmc_mfma.sh); per-launch averages over the launches of the batch", "kernels": {}}
+                     "--no-profile` (tools/gpu_call.sh mfma); per-launch averages over the launches of the batch", "kernels": {}}
     for label, sub in KERNELS.items():
         k = next((n for n in rows if sub in n), None)
         if k is None or "GRBM_GUI_ACTIVE" not in rows[k]:

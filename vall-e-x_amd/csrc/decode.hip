@@ -868,7 +868,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
   // SK + 1 dependent memory round trips at the head of the launch with only the first K/V tile in flight.
   f32x4 q4, k4, v4;
   {
-    // SK > 10 (experiment, skinny_qkv_bal_kernel): SK / 10 slabs of q, SK % 10 slabs of k and v
+    // SK > 10 (skinny_qkv_bal_kernel, the default in_proj of the 32-row chain since round 5): SK / 10 slabs of q, SK % 10 slabs of k and v
     constexpr int SKQ = SK > 10 ? SK / 10 : SK, SKV = SK > 10 ? SK % 10 : SK;
     const int NP = 3 * D_MODEL;
     const float* p = qkv_partial + (long)b * NP + h * D_HEAD + c * 4;
@@ -1330,7 +1330,7 @@ bool launch_dec_attn_qkv(const float* in_w, const float* in_b, float* kc, float*
 bool launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias, float* kc, float* vc, int Tmax,
                      const int* slot_meta, float* xp_out, float* part_o, float* part_ml, int nsplit, int batch,
                      const float* wo_heads, float* out_heads, hipStream_t s) {
-  if (splitk == 84) {                      // experiment: 8 slabs of q, 4 of k / v (skinny_qkv_bal_kernel)
+  if (splitk == 84) {                      // 8 slabs of q, 4 of k / v (skinny_qkv_bal_kernel)
     if (wo_heads && nsplit == 1)
       hipLaunchKernelGGL((dec_attn_kernel<true, 84>), dim3(N_HEAD, (batch + 1) / 2, 1), dim3(ATT_WAVES * 64 * 2), 0, s, kc, vc, slot_meta,
                          Tmax, batch, 1, 0, qkv_partial, qkv_bias, xp_out, part_o, part_ml, wo_heads, out_heads);

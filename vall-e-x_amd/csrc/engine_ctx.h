@@ -113,7 +113,7 @@ struct vx_ctx {
   int sb_qkv_rows = 4, sb_qkv_nsplit = 0;   // sb_qkv up to this many rows (VX_SB_QKV=n, 0 = off), forced split count (VX_SB_QKV_NSPLIT)
   bool sb_chain = false;           // the current micro-batch decodes on the small-batch chain (set by ar_prefill)
   bool sb_fuse = true;             // <= SB_ROWS rows: reduce+LN / combine folded into the consuming GEMM (VX_SB_FUSE=0: the general chain)
-  bool qkv_bal = false;            // experiment VX_QKV_BALANCED=1: the decode in_proj GEMM on 512 workgroups (8 K slices of q, 4 of k / v)
+  bool qkv_bal = true;             // the decode in_proj GEMM on 512 workgroups (8 K slices of q, 4 of k / v; VX_QKV_BALANCED=0: 384 x 4 slices)
   float* qk_new = nullptr;         // [MB][16][2][64]: q / 8 and k_new of the step's new token (dec_attn_qkv_kernel -> out_proj prologue)
   float *p_qkv = nullptr, *p_o = nullptr, *p_oh = nullptr, *p_logits = nullptr, *part_o = nullptr, *part_ml = nullptr;
   std::map<const unsigned short*, int> w_shift;   // f16x2: power-of-two scale exponent of every weight's planes

@@ -144,7 +144,7 @@ void launch_attn_full_probe(const float* qkv, float* out, const int* seq_off, co
 void launch_pack_weight(const float* W, int N, int K, float* Wp, int Npad, hipStream_t s);
 // partial[ks][b][n] = sum_{k in slice ks} x[b][k] * W[n][k];  xp is the packed activation image.
 void launch_skinny_gemm(const float* Wp, const float* xp, float* partial, int Npad, int K, int splitk, hipStream_t s);
-void launch_skinny_qkv_balanced(const float* Wp, const float* xp, float* partial, hipStream_t s);   // experiment
+void launch_skinny_qkv_balanced(const float* Wp, const float* xp, float* partial, hipStream_t s);   // 512 workgroups: q in 8 K slices, k / v in 4 (default since round 5)
 // h[b] = (resid? resid[b] : 0) + sum_ks partial[ks][b] + bias ; xp = pack(LN(h)*g+b)   (N = 1024)
 void launch_dec_reduce_ln_pack(const float* partial, int splitk, int npad, const float* bias, const float* resid,
                                float* h, const float* g, const float* b, float* xp, int batch, hipStream_t s);

@@ -149,7 +149,7 @@ int vx_finalize_weights(vx_ctx* c) {
   if ((e = dev_alloc(c, &c->xp, (size_t)MB * d))) return e;
   if ((e = dev_alloc(c, &c->xp_att, (size_t)MB * d))) return e;
   if ((e = dev_alloc(c, &c->xp4, (size_t)2 * MB * f))) return e;   // linear1's two split-K slabs, packed image
-  if (const char* ev = getenv("VX_QKV_BALANCED")) c->qkv_bal = ev[0] == '1';
+  if (const char* ev = getenv("VX_QKV_BALANCED")) c->qkv_bal = !(ev[0] == '0');
   if ((e = dev_alloc(c, &c->p_qkv, (size_t)std::max(SK_QKV, 8) * MB * 3 * d))) return e;
   if ((e = dev_alloc(c, &c->p_o, (size_t)std::max(SK_OUT, SK_L2) * MB * d))) return e;
   if ((e = dev_alloc(c, &c->p_oh, (size_t)N_HEAD * MB * d))) return e;
