@@ -19,7 +19,7 @@ def test_bench_runs_its_collectives_over_rccl_with_a_world_of_one():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rccl-single", "--steps", "1", "--warmup", "0",
-                        "--no-cpu-baseline", "--no-ref-arith", "--no-throughput-leg", "--no-profile"],
+                        "--no-cpu-baseline", "--no-ref-arith", "--no-profile"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]

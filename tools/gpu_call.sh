@@ -16,6 +16,7 @@
 #   env_ab VAR ROUNDS [c_bench args]                the C client with VAR=0 / VAR=1 alternating (ONE library, a runtime switch)
 #   lib_ab "base v1 v2" ROUNDS [c_bench args]       the C client on complete library variants (tools/devx_<name>/, _build.py --variant)
 #   gemm_operands                  is gemm_f16x2 power- or schedule-bound: the same launch on random / zero-tail / zero / constant operands
+#   gemm_f32_ab [ROUNDS]           the fp32-MFMA GEMM kernels (register-staged / LDS-DMA 256 x 128 / LDS-DMA 128 x 128) on the four NAR shapes
 #   power_bench                    board power + sclk from sysfs (tools/power_watch.c) beside two runs of the C client
 #   evidence RND [ARITH]           rocprofv3 --kernel-trace summary + a separate --pmc FETCH_SIZE pass of `bench.py --steps 1 [--arith ARITH]`
 #   mfma RND [ARITH]               three more separate --pmc passes (MFMA / VALU busy, issue stalls) of the same command
@@ -115,6 +116,19 @@ step_gemm_operands() {
     echo "== fp32 MFMA kernel, QKV shape (the reference-arithmetic leg's GEMM)"
     timeout 90 /tmp/c_gemm 31616 3072 1024 0 6
   } 2>&1 | tee gpurun_out/${TAG}_gemm_operands.txt
+}
+step_gemm_f32_ab() {
+  gcc $CF tools/c_gemm.c $LF -o /tmp/c_gemm || { echo "c_gemm: compile failed"; return 1; }
+  local rounds="${1:-2}"
+  {
+    for shape in "31616 3072 1024" "31616 1024 1024" "31616 4096 1024" "31616 1024 4096" "12288 3072 1024"; do
+      for r in $(seq 1 "$rounds"); do
+        for k in 3 4 5; do
+          VX_C_GEMM_MODES=random timeout 90 /tmp/c_gemm $shape $k 6 | tail -1 | sed "s/^/shape $shape kernel $k: /"
+        done
+      done
+    done
+  } 2>&1 | tee gpurun_out/${TAG}_gemm_f32_ab.txt
 }
 step_power_bench() {
   need_cbench || return 1

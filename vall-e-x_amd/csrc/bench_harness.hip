@@ -170,15 +170,16 @@ extern "C" int vx_dev_gemm_stamps(unsigned long long* out) { dev_read_gemm_stamp
 #endif
 
 // Stand-alone GEMM micro-benchmark on scratch buffers (kernel development aid; never on the product path):
-// kernel 0 = gemm_f32, 1 = gemm_bf16x3, 2 = gemm_bf16x3_dma, 6 = gemm_f16x2 (the default of the model path);
+// kernel 0 = gemm_f32 (3 / 4 / 5: its register-staged / LDS-DMA 256 x 128 / LDS-DMA 128 x 128 kernel forced), 1 = gemm_bf16x3,
+// 2 = gemm_bf16x3_dma, 6 = gemm_f16x2 (the default of the model path);
 // 11-13 / 21-24 = timing probes of the bf16x3 kernels (VX_DEV_PROBES builds only).  Reports the average launch time and the max abs
 // difference of the first and last 256 output rows against the fp32-MFMA kernel.
 static int bench_gemm_impl(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t kernel, int32_t reps, double* avg_us,
                            double* max_abs_diff, double* clock_mhz) {
   if (!c || M <= 0 || N <= 0 || K <= 0 || K % 32 || N % 4 || reps <= 0 || !avg_us || !max_abs_diff) return VX_EINVAL;
 #ifndef VX_DEV_PROBES
-  if (kernel != 0 && kernel != 1 && kernel != 2 && (kernel < 6 || kernel > 10))
-    FAIL(VX_EINVAL, "kernel must be 0, 1, 2 or 6 .. 10 (probes and the priority variants 12 / 13 need a VX_DEV_PROBES build)");
+  if (kernel < 0 || kernel > 10)
+    FAIL(VX_EINVAL, "kernel must be 0 .. 10 (probes and the priority variants 12 / 13 need a VX_DEV_PROBES build)");
 #endif
   HIPCHK(hipSetDevice(c->dev));
   float *A = nullptr, *Wt = nullptr, *C0 = nullptr, *C1 = nullptr;
@@ -220,7 +221,7 @@ static int bench_gemm_impl(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t k
   }
   GemmArgs g0{};
   g0.A = A; g0.lda = K; g0.W = Wt; g0.ldw = K; g0.C = C0; g0.ldc = N; g0.M = M; g0.N = N; g0.K = K; g0.act = ACT_NONE;
-  launch_gemm_f32(g0, c->stream);
+  launch_gemm_f32(g0, c->stream, 1);                                     // the comparison baseline: the register-staged fp32 kernel
   if ((kernel >= 6 && kernel <= 13) || kernel >= 61) {   // fp16 head / tail planes
     launch_split2h(A, K, M, K, nullptr, A3, h2_plane(M, K, H2_TILE_A), H2_TILE_A, nullptr, H2_ACT_SCALE, c->stream);
     launch_split2h(Wt, K, N, K, nullptr, W3, h2_plane(N, K, H2_TILE_W), H2_TILE_W, nullptr, 16384.0f, c->stream);   // |w| < 1
@@ -236,7 +237,8 @@ static int bench_gemm_impl(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t k
   GemmArgs g1 = g0;
   g1.C = C1;
   auto run = [&]() {
-    if (kernel == 0) launch_gemm_f32(g1, c->stream);
+    if (kernel == 0) launch_gemm_f32(g1, c->stream);                       // fp32 MFMA, the product's choice of kernel
+    else if (kernel >= 3 && kernel <= 5) launch_gemm_f32(g1, c->stream, kernel - 2);   // 3 register-staged / 4 LDS-DMA 256 x 128 / 5 LDS-DMA 128 x 128
     else if (kernel == 1) launch_gemm_bf16x3(gx, c->stream);
     else if (kernel == 2) launch_gemm_bf16x3_dma(gx, c->stream);
     else if (kernel == 6) launch_gemm_f16x2(gx, c->stream);              // the product's choice of tile

@@ -14,6 +14,9 @@
 // k-permutation: one ds_read_b128 gives a lane 4 consecutive k of its row; lanes 0-31 take k0..k0+3 and lanes
 // 32-63 take k0+4..k0+7.  MFMA step j then contracts k = k0 + 4*(lane>>5) + j for BOTH operands, which is a
 // bijection of the 8 k's onto (step, half) -- the sum is the same set of products (order differs only).
+#include <stdint.h>
+#include <stdlib.h>
+
 #include "vx_common.h"
 
 namespace vx {
@@ -160,10 +163,202 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
-void launch_gemm_f32(const GemmArgs& g, hipStream_t s) {
-  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-  if (tiles <= 0) return;
-  hipLaunchKernelGGL(gemm_f32_kernel, dim3(tiles), dim3(256), 0, s, g);
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same GEMM for the long row sets of the reference-arithmetic mode (vx_config.arith = f32: every transformer projection of the
+// AR prefill and of the 7 NAR stages, M = 12 288 .. 31 616 packed rows, N a multiple of 128): operand tiles go global -> LDS with
+// global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass) into TWO LDS stages, ONE rendezvous per K tile, fragments of k-block
+// kb + 1 read while the 16 MFMAs of kb run.  Tile 256 (M) x 128 (N) x 32 (K), 8 waves 4 x 2, wave tile 64 x 64 as in gemm_f32_kernel
+// -- per output element the SAME sequence of v_mfma_f32_32x32x2_f32 with the same operands (k-blocks of 8 in order, the k-permutation
+// of the header comment), so the two kernels agree bit for bit.
+// LDS image: a row is the 32 floats of the K tile = 128 B = eight 16-B chunks; chunk c of row r sits in slot c ^ ((r >> 1) & 7): the 16
+// lanes a ds_read_b128 serves together (rows r .. r + 15, one chunk index) land in 16 different 16-B slots of the 256-B bank row.  The
+// swizzle is applied on the GLOBAL side of the DMA (an instruction writes 1 KiB = 8 rows linearly: lane -> row l >> 3, slot l & 7, and
+// fetches chunk slot ^ swizzle of its row; every row is still one full 128-B line).
+namespace {
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
+}  // namespace
+
+template <int TM>
+__global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_f32_dma_kernel(GemmArgs g) {
+  constexpr int NWAVE = TM / 32;                                  // 8 (4 x 2) or 4 (2 x 2) waves
+  constexpr int A_BYTES = TM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;     // 48 / 32 KiB per stage
+  constexpr int NDMA = STAGE / (NWAVE * 1024);                    // 1 KiB DMA instructions per wave and stage: 6 / 8
+  constexpr int NA = TM / 8;                                      // ... the first NA of a stage fetch A (8 rows each)
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+
+  constexpr int GM = TM == 256 ? 8 : 16;
+  const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n;
+  int wg = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int per_group = GM * tiles_n;
+  const int grp = wg / per_group, in_grp = wg - grp * per_group;
+  const int gm0 = grp * GM;
+  const int gm_rows = (tiles_m - gm0 < GM) ? tiles_m - gm0 : GM;
+  const int tm = gm0 + in_grp % gm_rows, tn = in_grp / gm_rows;
+  const int m0 = tm * TM, n0 = tn * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1, hi = lane >> 5, l31 = lane & 31;
+
+  // DMA plan: instruction q = wid * NDMA + j of a stage covers rows 8 q' .. 8 q' + 7 of A (q < NA) or of W
+  const float* src[NDMA];
+  int lds_off[NDMA];
+#pragma unroll
+  for (int j = 0; j < NDMA; ++j) {
+    const int q = wid * NDMA + j;
+    const bool isA = q < NA;
+    const int row = (isA ? q : q - NA) * 8 + (lane >> 3);
+    const int ch = (lane & 7) ^ ((row >> 1) & 7);
+    if (isA) {
+      int m = m0 + row;
+      m = m < g.M ? m : g.M - 1;                                  // rows past M: clamped, never stored
+      const long arow = g.row_gather ? g.row_gather[m] : m;
+      src[j] = g.A + arow * (long)g.lda + ch * 4;
+    } else {
+      int n = n0 + row;
+      n = n < g.N ? n : g.N - 1;
+      src[j] = g.W + (long)n * g.ldw + ch * 4;
+    }
+    lds_off[j] = (isA ? 0 : A_BYTES) + (isA ? q : q - NA) * 1024;
+  }
+  auto dma = [&](int stage, int kt) {
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + kt * BK), (lptr_t)(lds + stage * STAGE + lds_off[j]), 16, 0, 0);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses: row (wm * 64 + i * 32 + l31) of A, (wn * 64 + i * 32 + l31) of W; chunk 2 kb + hi, swizzled by (l31 >> 1) & 7
+  const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)lds;
+  const unsigned swz = (unsigned)((l31 >> 1) & 7);
+  const unsigned a_base = lds0 + (unsigned)((wm * 64 + l31) * 128), w_base = lds0 + (unsigned)(A_BYTES + (wn * 64 + l31) * 128);
+  // inline-asm reads: for a C++ LDS load the compiler cannot tell the stage being filled from the stage being read and waits for the
+  // DMA (vmcnt(0)) in front of every fragment read; the hazards are ordered by the rendezvous below
+  auto frags = [&](int stage, int kb, f32x4 (&a)[2], f32x4 (&b)[2]) {
+    const unsigned co = (unsigned)(stage * STAGE) + ((((unsigned)(2 * kb + hi)) ^ swz) << 4);
+    asm volatile("ds_read_b128 %0, %1" : "=v"(a[0]) : "v"(a_base + co));
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a[1]) : "v"(a_base + co));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(b[0]) : "v"(w_base + co));
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(b[1]) : "v"(w_base + co));
+  };
+  auto mfmas = [&](const f32x4 (&a)[2], const f32x4 (&b)[2]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[jn][j], a[i][j], acc[i][jn], 0, 0, 0);
+  };
+
+  const int nk = g.K / BK;
+  f32x4 a0[2], b0[2], a1[2], b1[2];
+  dma(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int st = kt & 1;
+    // rendezvous: this wave's requests of tile kt have landed (vmcnt) and -- behind the barrier -- everybody's; every wave is past its
+    // fragment reads of tile kt - 1 (their data fed MFMAs that were issued before the barrier), so the other stage may be refilled
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    frags(st, 0, a0, b0);
+    if (kt + 1 < nk) dma(st ^ 1, kt + 1);
+    frags(st, 1, a1, b1);
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0[0]), "+v"(a0[1]), "+v"(b0[0]), "+v"(b0[1]));
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    frags(st, 2, a0, b0);
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a1[0]), "+v"(a1[1]), "+v"(b1[0]), "+v"(b1[1]));
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    frags(st, 3, a1, b1);
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0[0]), "+v"(a0[1]), "+v"(b0[0]), "+v"(b0[1]));
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1[0]), "+v"(a1[1]), "+v"(b1[0]), "+v"(b1[1]));
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(a1, b1);
+  }
+
+  // epilogue: as gemm_f32_kernel (a lane owns one output row and 4-element runs of consecutive n)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm * 64 + i * 32 + l31;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int n = n0 + wn * 64 + jn * 32 + 8 * g4 + 4 * hi;
+        if (n >= g.N) continue;
+        f32x4 v = {acc[i][jn][4 * g4], acc[i][jn][4 * g4 + 1], acc[i][jn][4 * g4 + 2], acc[i][jn][4 * g4 + 3]};
+        if (g.bias) {
+          const f32x4 bi = *reinterpret_cast<const f32x4*>(g.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bi[e];
+        }
+        if (g.act == ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (g.act == ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        } else if (g.act == ACT_ELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : expm1f(v[e]);
+        }
+        if (g.colscale) {
+          const f32x4 cs = *reinterpret_cast<const f32x4*>(g.colscale + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] * cs[e];
+        }
+        if (g.resid) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(g.resid + (long)m * g.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rr[e] + v[e];
+        }
+        *reinterpret_cast<f32x4*>(g.C + (long)m * g.ldc + n) = v;
+      }
+    }
+  }
+}
+
+// variant 0: the product's choice -- the LDS-DMA kernel for long row sets whose operands it can address (16-B aligned rows), the
+// register-staged kernel otherwise (Vocos / EnCodec: short row sets, N = 1282 / 1025 ...);  1 / 2 / 3: register-staged / DMA 256 x 128 /
+// DMA 128 x 128 forced (A/B; VX_GEMM_F32_VARIANT in the environment forces one for a whole process)
+void launch_gemm_f32(const GemmArgs& g, hipStream_t s, int variant) {
+  if (g.M <= 0 || g.N <= 0) return;
+  if (variant == 0) {
+    static const int env = [] { const char* e = getenv("VX_GEMM_F32_VARIANT"); return e ? atoi(e) : 0; }();
+    variant = env;
+  }
+  const bool dma_ok = g.K % BK == 0 && g.lda % 4 == 0 && g.ldw % 4 == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0 &&
+                      (reinterpret_cast<uintptr_t>(g.W) & 15) == 0;
+  if (variant == 0) variant = (dma_ok && g.M >= 2048 && g.N % BN == 0) ? 2 : 1;
+  if (variant != 1 && !dma_ok) variant = 1;
+  if (variant == 2) {
+    const int tiles = ((g.M + 255) / 256) * ((g.N + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm_f32_dma_kernel<256>, dim3(tiles), dim3(512), 0, s, g);
+  } else if (variant == 3) {
+    const int tiles = ((g.M + 127) / 128) * ((g.N + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm_f32_dma_kernel<128>, dim3(tiles), dim3(256), 0, s, g);
+  } else {
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(tiles), dim3(256), 0, s, g);
+  }
 }
 
 }  // namespace vx

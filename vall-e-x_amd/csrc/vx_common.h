@@ -36,7 +36,7 @@ struct GemmArgs {
   int act;
   const int* row_gather;    // optional: A row index per output row (null = identity)
 };
-void launch_gemm_f32(const GemmArgs& g, hipStream_t s);
+void launch_gemm_f32(const GemmArgs& g, hipStream_t s, int variant = 0);   // variant: gemm_f32.hip (0 = product choice)
 
 // ---- fp32-class GEMMs on the 16-bit matrix cores ----------------------------------------------------------------
 // Operands are pre-split planes, each K-tile-major [K/32][rows][32] 16-bit; same epilogue contract as GemmArgs.  K % 32 == 0.
