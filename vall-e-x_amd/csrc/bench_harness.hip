@@ -87,7 +87,8 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
     auto attn_l = [&](int r) {
       const int l = r % c->NL;
       const bool fused = c->fuse_out && c->nsplit == 1;
-      launch_dec_attn(c->p_qkv, SK_QKV, c->ar[l].in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax,
+      // slab counts of the product's in_proj (84 = 8 slabs of q, 4 of k / v: skinny_qkv_bal_kernel)
+      launch_dec_attn(c->p_qkv, c->qkv_bal ? 84 : SK_QKV, c->ar[l].in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax,
                       c->slot_meta, c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, fused ? c->ar[l].out_wh : nullptr, c->p_oh,
                       c->stream);
     };
@@ -99,7 +100,8 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
   } else if (which == 1) {
     const LayerW& L = c->ar[0];
     auto seq = [&]() {
-      launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, c->stream);
+      if (c->qkv_bal) launch_skinny_qkv_balanced(L.in_wp, c->xp, c->p_qkv, c->stream);      // the in_proj the decode step runs
+      else launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, c->stream);
       launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, c->stream);
       launch_skinny16_relu_pack(L.l1_wp, c->xp, L.l1_b, c->xp4, D_FF, D_MODEL, c->stream);
       launch_skinny_gemm(L.l2_wp, c->xp4, c->p_o, D_MODEL, D_FF, SK_L2, c->stream);
