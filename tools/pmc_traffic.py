@@ -26,7 +26,8 @@ KERNELS = {  # json suffix -> (kernel-name substring, what the algorithmic bytes
     "skinny16": "skinny16_relu_pack_kernel",
     "attn_full_x3": "attn_full_x3_kernel",
     "attn_full_h2": "attn_full_h2_kernel",
-    "gemm_f32": "gemm_f32_kernel",          # the reference-arithmetic leg (bench.py --arith f32): every projection
+    "gemm_f32": "gemm_f32_",                # the reference-arithmetic leg (bench.py --arith f32): every projection -- the LDS-DMA
+                                            # kernels gemm_f32_dma_kernel<256 / 128> and the register-staged gemm_f32_kernel, launch-weighted
     "attn_full": "attn_full_kernel",        # and the exact-fp32 full-sequence attention
     "gemm_bf16x3": "gemm_bf16x3_dma_kernel",
 }
