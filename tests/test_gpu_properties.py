@@ -181,13 +181,13 @@ def test_split_operand_gemm_kernels_agree_with_fp32():
 
 @pytest.mark.gpu
 def test_fp32_dma_gemm_kernels_equal_the_register_staged_kernel_bit_for_bit():
-    """round 5: the LDS-DMA fp32 GEMM kernels (256 x 128 and 128 x 128 tiles; the reference-arithmetic mode's projections) issue, per
+    """round 5: the LDS-DMA fp32 GEMM kernels (256 x 128, 128 x 128 and 256 x 256 tiles; the reference-arithmetic mode's projections) issue, per
     output element, the same v_mfma_f32_32x32x2_f32 sequence on the same operands as the register-staged kernel -- the harness compares
     the first and last 256 rows against that kernel: the difference must be EXACTLY zero, on the NAR shapes, on ragged row counts (edge
     rows clamped, never stored), on an N that does not fill its last column tile and on a single K tile; the product's own choice too"""
     import vallex_amd
     eng = vallex_amd.Engine(num_layers=1, max_batch=1, max_text=8, max_prompt=8, max_new=8, with_vocos=False)
     for (M, N, K) in ((31616, 3072, 1024), (12288, 1024, 4096), (2049, 1024, 1024), (983, 4096, 1024), (300, 1100, 32), (1, 128, 64)):
-        for kernel in (4, 5, 0):
+        for kernel in (4, 5, 14, 0):                          # LDS-DMA 256 x 128 / 128 x 128 / 256 x 256 forced, the product's choice
             us, diff = eng.bench_gemm(M, N, K, kernel, 1)
             assert diff == 0.0, (M, N, K, kernel, diff)

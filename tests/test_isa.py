@@ -156,21 +156,22 @@ def test_f16x2_attention_tile_loop(asm):
 
 def test_fp32_dma_gemm_tile_loop(asm):
     """the LDS-DMA fp32 GEMM of the reference-arithmetic mode (round 5): per K tile of 32 ONE rendezvous (counted wait + bare barrier),
-    64 fp32 MFMAs per wave (2 x 2 blocks x 16 k2 steps), 16 fragment reads, the stage's LDS-DMA requests (6 x 1 KiB per wave for the
-    256 x 128 tile), no ds_write pass, nothing spilled, two waves per SIMD"""
+    64 (128 for the 256 x 256 tile) fp32 MFMAs per wave (2 x 2 or 2 x 4 blocks x 16 k2 steps), 16 (24) fragment reads, the stage's LDS-DMA
+    requests (6 x 1 KiB per wave for the 256 x 128 tile), no ds_write pass, nothing spilled, two waves per SIMD"""
     lines = asm("gemm_f32.hip")
-    for sym, name, ndma, lds in ((r"_ZN2vx19gemm_f32_dma_kernelILi256EEE", "gemm_f32_dma_kernelILi256E", 6, 98304),
-                                 (r"_ZN2vx19gemm_f32_dma_kernelILi128EEE", "gemm_f32_dma_kernelILi128E", 8, 65536)):
+    for sym, name, ndma, lds, nj in ((r"_ZN2vx19gemm_f32_dma_kernelILi256ELi128EEE", "gemm_f32_dma_kernelILi256ELi128E", 6, 98304, 2),
+                                     (r"_ZN2vx19gemm_f32_dma_kernelILi128ELi128EEE", "gemm_f32_dma_kernelILi128ELi128E", 8, 65536, 2),
+                                     (r"_ZN2vx19gemm_f32_dma_kernelILi256ELi256EEE", "gemm_f32_dma_kernelILi256ELi256E", 8, 131072, 4)):
         body = kernel_body(lines, sym)
         main = max(loops(body), key=lambda lp: count(lp, r"v_mfma"))
-        assert count(main, r"v_mfma_f32_32x32x2_f32") == 64, name
+        assert count(main, r"v_mfma_f32_32x32x2_f32") == 32 * nj, name       # 2 x nj blocks x 16 k2 steps
         assert count(main, r"s_barrier") == 1, name
-        assert count(main, r"ds_read_b128") == 16 and count(main, r"ds_write") == 0, name
+        assert count(main, r"ds_read_b128") == 4 * (2 + nj) and count(main, r"ds_write") == 0, name
         # the compiler lays the `kt + 1 < nk` request block out behind the loop's backward branch: count over the kernel = prologue + loop
         assert count(body, r"global_load_lds_dwordx4") == 2 * ndma, name
         assert count(main, r"scratch_|buffer_store|buffer_load") == 0, name
         # the fragments of a k-block are waited for with the NEXT block's four reads still in flight, never with vmcnt(0) in between
         waits = [ln for ln in main if ln.startswith("s_waitcnt")]
-        assert sum("vmcnt(0)" in w for w in waits) == 1 and sum("lgkmcnt(4)" in w for w in waits) >= 3, waits
+        assert sum("vmcnt(0)" in w for w in waits) == 1 and sum(f"lgkmcnt({2 + nj})" in w for w in waits) >= 3, waits
         assert metadata(lines, name, "private_segment_fixed_size") == 0
-        assert metadata(lines, name, "vgpr_count") <= 128 and metadata(lines, name, "group_segment_fixed_size") == lds
+        assert metadata(lines, name, "vgpr_count") <= (128 if nj == 2 else 256) and metadata(lines, name, "group_segment_fixed_size") == lds

@@ -4,8 +4,8 @@
  *
  *   gcc -std=c99 -O2 -Wall -Wextra -Werror -pedantic -Iinclude tools/c_gemm.c -Lvall-e-x_amd/csrc -lvallex_hip \
  *       -Wl,-rpath,$PWD/vall-e-x_amd/csrc -o /tmp/c_gemm
- *   /tmp/c_gemm [M N K [kernel [reps]]]        kernel: 0 fp32 MFMA (3 / 4 / 5: register-staged / LDS-DMA 256 x 128 / LDS-DMA 128 x 128
- *                                              forced), 1 bf16x3, 2 bf16x3 + LDS-DMA, 6 f16x2 (product), 8 f16x2 256 x 256
+ *   /tmp/c_gemm [M N K [kernel [reps]]]        kernel: 0 fp32 MFMA (3 / 4 / 5 / 14: register-staged / LDS-DMA 256 x 128 / LDS-DMA
+ *                                              128 x 128 / LDS-DMA 256 x 256 forced), 1 bf16x3, 2 bf16x3 + LDS-DMA, 6 f16x2 (product), 8 f16x2 256 x 256
  *
  * The question it answers ("where round 5 starts"): is gemm_f16x2 bound by its schedule or by the board's power
  * limit?  Same launches, same bytes moved, quieter operands (zero fp16 tails / all zero): faster and a higher clock = power. */
@@ -27,7 +27,7 @@ int main(int argc, char** argv) {
   int rc = vx_create(0, &cfg, &ctx);
   if (rc != VX_OK) { fprintf(stderr, "vx_create -> %d: %s\n", rc, vx_last_error(NULL)); return 10; }
   const char* modes[4] = {"random", "zero_tail", "zero", "const"};
-  const double mfma_per_product = (kernel == 0 || (kernel >= 3 && kernel <= 5)) ? 1.0 : (kernel == 1 || kernel == 2 ? 6.0 : 3.0);   /* 16-bit MFMAs per fp32 block */
+  const double mfma_per_product = (kernel == 0 || (kernel >= 3 && kernel <= 5) || kernel == 14) ? 1.0 : (kernel == 1 || kernel == 2 ? 6.0 : 3.0);   /* 16-bit MFMAs per fp32 block */
   printf("kernel %d  M %d  N %d  K %d  reps %d\n%-10s %10s %12s %12s %10s %12s\n", kernel, M, N, K, reps, "operands", "us", "fp32-eq TF",
          "MFMA PF", "clock MHz", "max|diff|");
   const char* only = getenv("VX_C_GEMM_MODES");        /* e.g. "random": one pattern, one pass (A/B of kernels) */
@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
       rc = vx_bench_gemm_clock(ctx, M, N, K, kernel, reps, &us, &diff, &mhz);
       if (rc != VX_OK) { fprintf(stderr, "vx_bench_gemm_clock -> %d: %s\n", rc, vx_last_error(ctx)); vx_destroy(ctx); return 11; }
       const double tf = 2.0 * M * (double)N * K / (us * 1e-6) * 1e-12;
-      printf("%-10s %10.1f %12.1f %12.3f %10.0f %12.3g\n", modes[m], us, tf, (kernel == 0 || (kernel >= 3 && kernel <= 5)) ? 0.0 : tf * mfma_per_product * 1e-3, mhz, diff);
+      printf("%-10s %10.1f %12.1f %12.3f %10.0f %12.3g\n", modes[m], us, tf, (kernel == 0 || (kernel >= 3 && kernel <= 5) || kernel == 14) ? 0.0 : tf * mfma_per_product * 1e-3, mhz, diff);
     }
   vx_destroy(ctx);
   return 0;

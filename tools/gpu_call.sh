@@ -123,7 +123,7 @@ step_gemm_f32_ab() {
   {
     for shape in "31616 3072 1024" "31616 1024 1024" "31616 4096 1024" "31616 1024 4096" "12288 3072 1024"; do
       for r in $(seq 1 "$rounds"); do
-        for k in 3 4 5; do
+        for k in ${GEMM_F32_KERNELS:-3 4 5 14}; do
           VX_C_GEMM_MODES=random timeout 90 /tmp/c_gemm $shape $k 6 | tail -1 | sed "s/^/shape $shape kernel $k: /"
         done
       done

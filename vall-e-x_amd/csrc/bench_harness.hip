@@ -180,8 +180,8 @@ static int bench_gemm_impl(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t k
                            double* max_abs_diff, double* clock_mhz) {
   if (!c || M <= 0 || N <= 0 || K <= 0 || K % 32 || N % 4 || reps <= 0 || !avg_us || !max_abs_diff) return VX_EINVAL;
 #ifndef VX_DEV_PROBES
-  if (kernel < 0 || kernel > 10)
-    FAIL(VX_EINVAL, "kernel must be 0 .. 10 (probes and the priority variants 12 / 13 need a VX_DEV_PROBES build)");
+  if (kernel < 0 || (kernel > 10 && kernel != 14))
+    FAIL(VX_EINVAL, "kernel must be 0 .. 10 or 14 (probes and the priority variants 12 / 13 need a VX_DEV_PROBES build)");
 #endif
   HIPCHK(hipSetDevice(c->dev));
   float *A = nullptr, *Wt = nullptr, *C0 = nullptr, *C1 = nullptr;
@@ -241,6 +241,7 @@ static int bench_gemm_impl(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t k
   auto run = [&]() {
     if (kernel == 0) launch_gemm_f32(g1, c->stream);                       // fp32 MFMA, the product's choice of kernel
     else if (kernel >= 3 && kernel <= 5) launch_gemm_f32(g1, c->stream, kernel - 2);   // 3 register-staged / 4 LDS-DMA 256 x 128 / 5 LDS-DMA 128 x 128
+    else if (kernel == 14) launch_gemm_f32(g1, c->stream, 4);                          // LDS-DMA 256 x 256
     else if (kernel == 1) launch_gemm_bf16x3(gx, c->stream);
     else if (kernel == 2) launch_gemm_bf16x3_dma(gx, c->stream);
     else if (kernel == 6) launch_gemm_f16x2(gx, c->stream);              // the product's choice of tile

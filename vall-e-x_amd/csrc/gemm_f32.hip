@@ -179,16 +179,17 @@ typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 }  // namespace
 
-template <int TM>
+template <int TM, int TN>
 __global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_f32_dma_kernel(GemmArgs g) {
   constexpr int NWAVE = TM / 32;                                  // 8 (4 x 2) or 4 (2 x 2) waves
-  constexpr int A_BYTES = TM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;     // 48 / 32 KiB per stage
-  constexpr int NDMA = STAGE / (NWAVE * 1024);                    // 1 KiB DMA instructions per wave and stage: 6 / 8
+  constexpr int NJ = TN / 64;                                     // 32-column blocks of a wave: 2 (wave tile 64 x 64) or 4 (64 x 128)
+  constexpr int A_BYTES = TM * 128, W_BYTES = TN * 128, STAGE = A_BYTES + W_BYTES;     // 64 / 48 / 32 KiB per stage
+  constexpr int NDMA = STAGE / (NWAVE * 1024);                    // 1 KiB DMA instructions per wave and stage: 8 / 6 / 8
   constexpr int NA = TM / 8;                                      // ... the first NA of a stage fetch A (8 rows each)
   __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
 
   constexpr int GM = TM == 256 ? 8 : 16;
-  const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + BN - 1) / BN;
+  const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
   const int nwg = tiles_m * tiles_n;
   int wg = blockIdx.x;
   {
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_f32_dma_kernel
   const int gm0 = grp * GM;
   const int gm_rows = (tiles_m - gm0 < GM) ? tiles_m - gm0 : GM;
   const int tm = gm0 + in_grp % gm_rows, tn = in_grp / gm_rows;
-  const int m0 = tm * TM, n0 = tn * BN;
+  const int m0 = tm * TM, n0 = tn * TN;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1, hi = lane >> 5, l31 = lane & 31;
@@ -232,38 +233,54 @@ __global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_f32_dma_kernel
       __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + kt * BK), (lptr_t)(lds + stage * STAGE + lds_off[j]), 16, 0, 0);
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // fragment addresses: row (wm * 64 + i * 32 + l31) of A, (wn * 64 + i * 32 + l31) of W; chunk 2 kb + hi, swizzled by (l31 >> 1) & 7
+  // fragment addresses: row (wm * 64 + i * 32 + l31) of A, (wn * TN / 2 + i * 32 + l31) of W; chunk 2 kb + hi, swizzled by (l31 >> 1) & 7
   const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)lds;
   const unsigned swz = (unsigned)((l31 >> 1) & 7);
-  const unsigned a_base = lds0 + (unsigned)((wm * 64 + l31) * 128), w_base = lds0 + (unsigned)(A_BYTES + (wn * 64 + l31) * 128);
+  const unsigned a_base = lds0 + (unsigned)((wm * 64 + l31) * 128), w_base = lds0 + (unsigned)(A_BYTES + (wn * (TN / 2) + l31) * 128);
   // inline-asm reads: for a C++ LDS load the compiler cannot tell the stage being filled from the stage being read and waits for the
   // DMA (vmcnt(0)) in front of every fragment read; the hazards are ordered by the rendezvous below
-  auto frags = [&](int stage, int kb, f32x4 (&a)[2], f32x4 (&b)[2]) {
+  auto frags = [&](int stage, int kb, f32x4 (&a)[2], f32x4 (&b)[NJ]) {
     const unsigned co = (unsigned)(stage * STAGE) + ((((unsigned)(2 * kb + hi)) ^ swz) << 4);
     asm volatile("ds_read_b128 %0, %1" : "=v"(a[0]) : "v"(a_base + co));
     asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a[1]) : "v"(a_base + co));
     asm volatile("ds_read_b128 %0, %1" : "=v"(b[0]) : "v"(w_base + co));
     asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(b[1]) : "v"(w_base + co));
+    if constexpr (NJ == 4) {
+      asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(b[2]) : "v"(w_base + co));
+      asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(b[3]) : "v"(w_base + co));
+    }
   };
-  auto mfmas = [&](const f32x4 (&a)[2], const f32x4 (&b)[2]) {
+  auto mfmas = [&](const f32x4 (&a)[2], const f32x4 (&b)[NJ]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[jn][j], a[i][j], acc[i][jn], 0, 0, 0);
+        for (int jn = 0; jn < NJ; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[jn][j], a[i][j], acc[i][jn], 0, 0, 0);
+  };
+  // wait until the OLDER of two fragment sets has arrived (the NFR reads of the younger one stay in flight); the set is named as
+  // in / out operands so that neither the compiler nor the scheduler moves its consumers above the wait
+  auto wait_set = [&](f32x4 (&a)[2], f32x4 (&b)[NJ], bool last) {
+    if constexpr (NJ == 4) {
+      if (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+      else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    } else {
+      if (last) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
+      else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   const int nk = g.K / BK;
-  f32x4 a0[2], b0[2], a1[2], b1[2];
+  f32x4 a0[2], b0[NJ], a1[2], b1[NJ];
   dma(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     const int st = kt & 1;
@@ -274,22 +291,18 @@ __global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_f32_dma_kernel
     frags(st, 0, a0, b0);
     if (kt + 1 < nk) dma(st ^ 1, kt + 1);
     frags(st, 1, a1, b1);
-    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0[0]), "+v"(a0[1]), "+v"(b0[0]), "+v"(b0[1]));
-    __builtin_amdgcn_sched_barrier(0);
+    wait_set(a0, b0, false);
     mfmas(a0, b0);
     __builtin_amdgcn_sched_barrier(0);
     frags(st, 2, a0, b0);
-    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a1[0]), "+v"(a1[1]), "+v"(b1[0]), "+v"(b1[1]));
-    __builtin_amdgcn_sched_barrier(0);
+    wait_set(a1, b1, false);
     mfmas(a1, b1);
     __builtin_amdgcn_sched_barrier(0);
     frags(st, 3, a1, b1);
-    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0[0]), "+v"(a0[1]), "+v"(b0[0]), "+v"(b0[1]));
-    __builtin_amdgcn_sched_barrier(0);
+    wait_set(a0, b0, false);
     mfmas(a0, b0);
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a1[0]), "+v"(a1[1]), "+v"(b1[0]), "+v"(b1[1]));
-    __builtin_amdgcn_sched_barrier(0);
+    wait_set(a1, b1, true);
     mfmas(a1, b1);
   }
 
@@ -299,10 +312,10 @@ __global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_f32_dma_kernel
     const int m = m0 + wm * 64 + i * 32 + l31;
     if (m >= g.M) continue;
 #pragma unroll
-    for (int jn = 0; jn < 2; ++jn) {
+    for (int jn = 0; jn < NJ; ++jn) {
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        const int n = n0 + wn * 64 + jn * 32 + 8 * g4 + 4 * hi;
+        const int n = n0 + wn * (TN / 2) + jn * 32 + 8 * g4 + 4 * hi;
         if (n >= g.N) continue;
         f32x4 v = {acc[i][jn][4 * g4], acc[i][jn][4 * g4 + 1], acc[i][jn][4 * g4 + 2], acc[i][jn][4 * g4 + 3]};
         if (g.bias) {
@@ -337,8 +350,8 @@ __global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_f32_dma_kernel
 }
 
 // variant 0: the product's choice -- the LDS-DMA kernel for long row sets whose operands it can address (16-B aligned rows), the
-// register-staged kernel otherwise (Vocos / EnCodec: short row sets, N = 1282 / 1025 ...);  1 / 2 / 3: register-staged / DMA 256 x 128 /
-// DMA 128 x 128 forced (A/B; VX_GEMM_F32_VARIANT in the environment forces one for a whole process)
+// register-staged kernel otherwise (Vocos / EnCodec: short row sets, N = 1282 / 1025 ...);  1 / 2 / 3 / 4: register-staged / DMA 256 x 128 /
+// DMA 128 x 128 / DMA 256 x 256 forced (A/B; VX_GEMM_F32_VARIANT in the environment forces one for a whole process)
 void launch_gemm_f32(const GemmArgs& g, hipStream_t s, int variant) {
   if (g.M <= 0 || g.N <= 0) return;
   if (variant == 0) {
@@ -354,10 +367,13 @@ void launch_gemm_f32(const GemmArgs& g, hipStream_t s, int variant) {
   if (variant != 1 && !dma_ok) variant = 1;
   if (variant == 2) {
     const int tiles = ((g.M + 255) / 256) * ((g.N + BN - 1) / BN);
-    hipLaunchKernelGGL(gemm_f32_dma_kernel<256>, dim3(tiles), dim3(512), 0, s, g);
+    hipLaunchKernelGGL((gemm_f32_dma_kernel<256, 128>), dim3(tiles), dim3(512), 0, s, g);
   } else if (variant == 3) {
     const int tiles = ((g.M + 127) / 128) * ((g.N + BN - 1) / BN);
-    hipLaunchKernelGGL(gemm_f32_dma_kernel<128>, dim3(tiles), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_f32_dma_kernel<128, 128>), dim3(tiles), dim3(256), 0, s, g);
+  } else if (variant == 4) {
+    const int tiles = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+    hipLaunchKernelGGL((gemm_f32_dma_kernel<256, 256>), dim3(tiles), dim3(512), 0, s, g);
   } else {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     hipLaunchKernelGGL(gemm_f32_kernel, dim3(tiles), dim3(256), 0, s, g);
