@@ -360,10 +360,12 @@ void launch_gemm_f32(const GemmArgs& g, hipStream_t s, int variant) {
   }
   const bool dma_ok = g.K % BK == 0 && g.lda % 4 == 0 && g.ldw % 4 == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0 &&
                       (reinterpret_cast<uintptr_t>(g.W) & 15) == 0;
-  // measured on MI355X (profiles/r05_gemm_f32_ab.log, the four NAR shapes at M = 31 616 and the prefill's M = 12 288, interleaved):
-  // 256 x 128 DMA tiles -4.0 / -4.5 / -1.4 / -3.4 % against the register-staged kernel at M = 31 616, +2 % at M = 12 288 (4.5 rounds of
-  // tiles on 256 CUs), where the 128 x 128 DMA tiles (two workgroups per CU) are -1.7 %; all three agree bit for bit
-  if (variant == 0) variant = !(dma_ok && g.N % BN == 0 && g.M >= 2048) ? 1 : (g.M >= 16384 ? 2 : 3);
+  // measured on MI355X (profiles/r05_gemm_f32_ab.log: the four NAR shapes at M = 31 616 and the prefill's M = 12 288, interleaved,
+  // random operands): against the register-staged kernel the 256 x 256 DMA tile is -7.5 / -6.6 / -6.5 / -7.7 % at M = 31 616 (the
+  // 256 x 128 one -4.4 / -4.8 / -2.1 / -2.6 %) and +13 % at M = 12 288 (48 x 12 tiles = 2.25 rounds on 256 CUs), where the 128 x 128 DMA
+  // tile (two workgroups per CU) is -1.3 %; all four kernels agree bit for bit
+  if (variant == 0)
+    variant = !(dma_ok && g.N % BN == 0 && g.M >= 2048) ? 1 : (g.M < 16384 ? 3 : (g.N % 256 == 0 ? 4 : 2));
   if (variant != 1 && !dma_ok) variant = 1;
   if (variant == 2) {
     const int tiles = ((g.M + 255) / 256) * ((g.N + BN - 1) / BN);
