@@ -14,8 +14,9 @@ import sys
 # 2.8-4.6 GHz), so a busy fraction relative to it means nothing there
 KERNELS = {"gemm_f16x2 (256x256 tiles)": "gemm_f16x2_kernel<256, 256", "attn_full_h2": "attn_full_h2_kernel",
            "gemm_f32 register-staged (Vocos head, short row sets)": "gemm_f32_kernel",
-           "gemm_f32 LDS-DMA 256 x 128 (every long projection with --arith f32)": "gemm_f32_dma_kernel<256>",
-           "gemm_f32 LDS-DMA 128 x 128 (--arith f32, prefill)": "gemm_f32_dma_kernel<128>", "attn_full (--arith f32)": "attn_full_kernel",
+           "gemm_f32 LDS-DMA 256 x 256 (every long projection with --arith f32)": "gemm_f32_dma_kernel<256, 256>",
+           "gemm_f32 LDS-DMA 256 x 128 (long row sets, N % 256 != 0: Vocos)": "gemm_f32_dma_kernel<256, 128>",
+           "gemm_f32 LDS-DMA 128 x 128 (--arith f32, prefill)": "gemm_f32_dma_kernel<128, 128>", "attn_full (--arith f32)": "attn_full_kernel",
            "gemm_bf16x3_dma (--arith bf16x3)": "gemm_bf16x3_dma_kernel", "attn_full_x3 (--arith bf16x3)": "attn_full_x3_kernel"}
 
 
