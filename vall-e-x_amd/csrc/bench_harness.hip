@@ -180,8 +180,8 @@ static int bench_gemm_impl(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t k
                            double* max_abs_diff, double* clock_mhz) {
   if (!c || M <= 0 || N <= 0 || K <= 0 || K % 32 || N % 4 || reps <= 0 || !avg_us || !max_abs_diff) return VX_EINVAL;
 #ifndef VX_DEV_PROBES
-  if (kernel < 0 || (kernel > 10 && kernel != 14))
-    FAIL(VX_EINVAL, "kernel must be 0 .. 10 or 14 (probes and the priority variants 12 / 13 need a VX_DEV_PROBES build)");
+  if (kernel < 0 || (kernel > 10 && kernel != 14 && kernel != 15))
+    FAIL(VX_EINVAL, "kernel must be 0 .. 10, 14 or 15 (probes and the priority variants 12 / 13 need a VX_DEV_PROBES build)");
 #endif
   HIPCHK(hipSetDevice(c->dev));
   float *A = nullptr, *Wt = nullptr, *C0 = nullptr, *C1 = nullptr;
@@ -224,7 +224,7 @@ static int bench_gemm_impl(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t k
   GemmArgs g0{};
   g0.A = A; g0.lda = K; g0.W = Wt; g0.ldw = K; g0.C = C0; g0.ldc = N; g0.M = M; g0.N = N; g0.K = K; g0.act = ACT_NONE;
   launch_gemm_f32(g0, c->stream, 1);                                     // the comparison baseline: the register-staged fp32 kernel
-  if ((kernel >= 6 && kernel <= 13) || kernel >= 61) {   // fp16 head / tail planes
+  if ((kernel >= 6 && kernel <= 13) || kernel == 15 || kernel >= 61) {   // fp16 head / tail planes
     launch_split2h(A, K, M, K, nullptr, A3, h2_plane(M, K, H2_TILE_A), H2_TILE_A, nullptr, H2_ACT_SCALE, c->stream);
     launch_split2h(Wt, K, N, K, nullptr, W3, h2_plane(N, K, H2_TILE_W), H2_TILE_W, nullptr, 16384.0f, c->stream);   // |w| < 1
   } else {
@@ -232,7 +232,7 @@ static int bench_gemm_impl(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t k
     launch_split3(Wt, K, N, K, nullptr, W3, (long)N * K, c->stream);
   }
   GemmX3Args gx{};
-  const bool h2 = (kernel >= 6 && kernel <= 13) || kernel >= 61;
+  const bool h2 = (kernel >= 6 && kernel <= 13) || kernel == 15 || kernel >= 61;
   gx.A = A3; gx.a_plane = h2 ? h2_plane(M, K, H2_TILE_A) : (long)M * K; gx.W = W3; gx.w_plane = h2 ? h2_plane(N, K, H2_TILE_W) : (long)N * K; gx.C = C1; gx.ldc = N; gx.M = M; gx.N = N; gx.K = K;
   gx.act = ACT_NONE;
   gx.descale = ldexpf(1.0f, -(H2_ACT_SHIFT + 14));
@@ -246,7 +246,8 @@ static int bench_gemm_impl(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t k
     else if (kernel == 2) launch_gemm_bf16x3_dma(gx, c->stream);
     else if (kernel == 6) launch_gemm_f16x2(gx, c->stream);              // the product's choice of tile
     else if (kernel == 7) launch_gemm_f16x2(gx, c->stream, 128);
-    else if (kernel == 8) launch_gemm_f16x2(gx, c->stream, 256);
+    else if (kernel == 8) launch_gemm_f16x2(gx, c->stream, 256);          // 256 x 256 tiles on the 8-wave kernel (64 x 128 per wave)
+    else if (kernel == 15) launch_gemm_f16x2(gx, c->stream, 257);         // 256 x 256 tiles on the 4-wave kernel (128 x 128 per wave)
     else if (kernel == 9) launch_gemm_f16x2(gx, c->stream, -128);         // 128 x 128 tiles (the short-row-set kernel) forced
     else if (kernel == 10) launch_gemm_f16x2(gx, c->stream, -129);        // ... with two LDS stages forced (A/B of the four-stage ring)
 #ifdef VX_DEV_PROBES

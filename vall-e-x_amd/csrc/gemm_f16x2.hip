@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "vx_common.h"
 
@@ -388,15 +389,229 @@ __global__ __launch_bounds__(TM * 2, (TM == 256 || NST == 4) ? 1 : 2) void gemm_
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Round 5: the 256 x 256 workgroup tile on FOUR waves of 128 x 128 (16 accumulator blocks = 256 accumulator registers in AGPRs, one
+// wave per SIMD): 16 fragment reads per 48 MFMAs (0.33 ds_read_b128 per MFMA instead of 0.5) -- what the operand-pattern test of
+// this round asked for (profiles/r05_gemm_operand_patterns.txt: the 8-wave kernel is power / clock-limited on real operands, so
+// only less data movement per MFMA pays).  A lone wave per SIMD has nobody to hide its waits, hence a complete software pipeline:
+//   * two fragment sets: the 16 fragments of the NEXT k16 step are read, one behind every third MFMA, while the 48 MFMAs of this
+//     step run (across the K-tile boundary too);
+//   * the ONE rendezvous of a K tile sits BETWEEN its two k16 steps;
+//   * the 16 LDS-DMA requests of tile kt + 2 are issued, one behind every third MFMA, during the second step of tile kt: they have a
+//     whole k16 step (>= 1 536 matrix-pipe cycles) left to land before the rendezvous of tile kt + 1 asks for them.
+// Inline-asm LDS reads with counted waits (a C++ LDS load behind an LDS-DMA makes the compiler wait for the DMA).  Same operand
+// planes, same LDS image and per output element the same MFMA sequence as gemm_f16x2_kernel => bit-identical sums.  Measured
+// against it on MI355X (profiles/r05_gemm_w128_ab.log, M = 31 616, interleaved, random operands): QKV 604 -> 518 us (-14 %), linear1
+// 841 -> 761 (-9.5 %), linear2 774 -> 718 (-7.3 %), out_proj 176 -> 173; on all-zero operands 0.62-0.71 of the 833 TF ceiling.
+__global__ __launch_bounds__(256, 1) void gemm_f16x2_w128_kernel(GemmX3Args g) {
+  constexpr int TN = 256, HA_PL = HM * HLD, HW_PL = TN * HLD, HSTAGE = 2 * HA_PL + 2 * HW_PL;     // 64 KiB per stage
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * HSTAGE];
+  constexpr int GM = 8;
+  const int tiles_m = (g.M + HM - 1) / HM, tiles_n = g.N / TN;
+  const int nwg = tiles_m * tiles_n;
+  int wg = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int per_group = GM * tiles_n;
+  const int grp = wg / per_group, in_grp = wg - grp * per_group;
+  const int gm0 = grp * GM;
+  const int gm_rows = (tiles_m - gm0 < GM) ? tiles_m - gm0 : GM;
+  const int tm = gm0 + in_grp % gm_rows, tn = in_grp / gm_rows;
+  const int m0 = tm * HM, n0 = tn * TN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1, hi = lane >> 5, l31 = lane & 31;
+
+  // DMA plan: wave w fetches ONE plane of a stage (0 / 1: A head / tail, 2 / 3: W head / tail): 16 instructions of 1 KiB = 16 rows
+  // each; in the tile-major planes the 256 rows x 32 of a K tile are one contiguous 16 KiB run, so instruction j is base + j KiB.
+  // Lane -> (row l / 4 of the 16, LDS chunk slot l % 4), swizzle on the global side (as in gemm_f16x2_kernel).
+  const bool isA = wid < 2;
+  const int pl = wid & 1;
+  const unsigned short* dbase = (isA ? g.A + pl * g.a_plane + (long)tm * (g.K / HK) * (HM * HK)
+                                     : g.W + pl * g.w_plane + (long)tn * (g.K / HK) * (WTR * HK)) +
+                                (long)(lane >> 2) * HK + (((lane & 3) ^ ((lane >> 4) & 3)) * 8);
+  const int dlds = (isA ? pl * HA_PL : 2 * HA_PL + pl * HW_PL);
+  auto dma1 = [&](int stage, int kt, int j) {
+    __builtin_amdgcn_global_load_lds((gptr_t)(dbase + (long)kt * (HM * HK) + j * 512), (lptr_t)(lds + stage * HSTAGE + dlds + j * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const unsigned lds0 = (unsigned)(unsigned long long)(lptr_t)lds;
+  const unsigned sw = (unsigned)((l31 >> 2) & 3);
+  const unsigned a_base = lds0 + (unsigned)((wm * 128 + l31) * HLD), w_base = lds0 + (unsigned)(2 * HA_PL + (wn * 128 + l31) * HLD);
+  // fragment f of a set: f < 8: W plane f / 4, block f % 4;  f >= 8: A block (f - 8) / 2, plane (f - 8) % 2
+  f16x8 F0[16], F1[16];
+#define VX_RD(DST, BASE, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(BASE), "n"(OFF))
+  auto rd1 = [&](f16x8 (&F)[16], unsigned co, int f) {
+    const unsigned wa = w_base + co, aa = a_base + co;
+    switch (f) {
+      case 0: VX_RD(F[0], wa, 0 * HW_PL + 0 * 2048); break;   case 1: VX_RD(F[1], wa, 0 * HW_PL + 1 * 2048); break;
+      case 2: VX_RD(F[2], wa, 0 * HW_PL + 2 * 2048); break;   case 3: VX_RD(F[3], wa, 0 * HW_PL + 3 * 2048); break;
+      case 4: VX_RD(F[4], wa, 1 * HW_PL + 0 * 2048); break;   case 5: VX_RD(F[5], wa, 1 * HW_PL + 1 * 2048); break;
+      case 6: VX_RD(F[6], wa, 1 * HW_PL + 2 * 2048); break;   case 7: VX_RD(F[7], wa, 1 * HW_PL + 3 * 2048); break;
+      case 8: VX_RD(F[8], aa, 0 * HA_PL + 0 * 2048); break;   case 9: VX_RD(F[9], aa, 1 * HA_PL + 0 * 2048); break;
+      case 10: VX_RD(F[10], aa, 0 * HA_PL + 1 * 2048); break; case 11: VX_RD(F[11], aa, 1 * HA_PL + 1 * 2048); break;
+      case 12: VX_RD(F[12], aa, 0 * HA_PL + 2 * 2048); break; case 13: VX_RD(F[13], aa, 1 * HA_PL + 2 * 2048); break;
+      case 14: VX_RD(F[14], aa, 0 * HA_PL + 3 * 2048); break; default: VX_RD(F[15], aa, 1 * HA_PL + 3 * 2048); break;
+    }
+  };
+  auto coff = [&](int stage, int s) { return (unsigned)(stage * HSTAGE) + (((unsigned)(2 * s + hi) ^ sw) << 4); };
+  auto wait_set = [&](f16x8 (&F)[16]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(F[4]), "+v"(F[5]), "+v"(F[6]), "+v"(F[7]), "+v"(F[8]), "+v"(F[9]),
+                   "+v"(F[10]), "+v"(F[11]), "+v"(F[12]), "+v"(F[13]), "+v"(F[14]), "+v"(F[15]));
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // one k16 step on set F: 48 MFMAs in gemm_f16x2_kernel's order (per block: tail.head, head.tail, head.head).  Behind every third
+  // MFMA: one fragment read of the other set (RD) and one LDS-DMA request (DM).
+  auto step = [&](const f16x8 (&F)[16], f16x8 (&G)[16], auto rd, unsigned rco, auto dm, int dstage, int dkt) {
+    int n = 0;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const int wp = p == 0 ? 1 : 0, ap = p == 1 ? 1 : 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) {
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[wp * 4 + jn], F[8 + 2 * i + ap], acc[i][jn], 0, 0, 0);
+          ++n;
+          if (n % 3 == 2 && (decltype(rd)::value || decltype(dm)::value)) {
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (decltype(rd)::value) rd1(G, rco, n / 3);
+            if constexpr (decltype(dm)::value) dma1(dstage, dkt, n / 3);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+    }
+  };
+  // one K tile: k16 step 0 on F0 (reading F1 <- the tile's second step), the rendezvous, k16 step 1 on F1 (RD: reading F0 <- the next
+  // tile's first step from the other stage; DM: requesting tile kt + 2 into this tile's stage)
+  auto ktile = [&](int kt, auto rd, auto dm) {
+    const int A = kt & 1, B = A ^ 1;
+    wait_set(F0);
+    step(F0, F1, std::true_type{}, coff(A, 1), std::false_type{}, 0, 0);
+    // the ONE rendezvous of the tile: this wave's requests of tile kt + 1 have landed (issued a whole k16 step ago or more), its
+    // reads of stage A are complete; behind the barrier the same holds for every wave: stage B may be read, stage A refilled
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(F1[0]), "+v"(F1[1]), "+v"(F1[2]), "+v"(F1[3]), "+v"(F1[4]), "+v"(F1[5]), "+v"(F1[6]), "+v"(F1[7]), "+v"(F1[8]),
+                   "+v"(F1[9]), "+v"(F1[10]), "+v"(F1[11]), "+v"(F1[12]), "+v"(F1[13]), "+v"(F1[14]), "+v"(F1[15])
+                 :: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    step(F1, F0, rd, coff(B, 0), dm, A, kt + 2);
+  };
+
+  const int nk = g.K / HK;                                        // >= 2 (launch_gemm_f16x2 checks)
+#pragma unroll
+  for (int j = 0; j < 16; ++j) dma1(0, 0, j);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  {
+    const unsigned co = coff(0, 0);
+#pragma unroll
+    for (int f = 0; f < 16; ++f) rd1(F0, co, f);
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) dma1(1, 1, j);
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) ktile(kt, std::true_type{}, std::true_type{});
+  ktile(kt, std::true_type{}, std::false_type{});
+  ktile(kt + 1, std::false_type{}, std::false_type{});
+#undef VX_RD
+
+  // epilogue: as gemm_f16x2_kernel (fp32 rows, or the NEXT GEMM's operand planes), 4 x 4 blocks of 32 x 32 per wave
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 128 + i * 32 + l31;
+    if (m >= g.M) continue;
+    const int mr = (g.resid && g.resid_rows) ? g.resid_rows[m] : m;
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn) {
+      unsigned hw[4][2], tw[4][2];
+      bool bad = false;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int n = n0 + wn * 128 + jn * 32 + 8 * g4 + 4 * hi;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][jn][4 * g4 + e] * g.descale;
+        if (g.bias) {
+          const f32x4 bi = *reinterpret_cast<const f32x4*>(g.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bi[e];
+        }
+        if (g.act == ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (g.resid) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(g.resid + (long)mr * g.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rr[e] + v[e];
+        }
+        if (!g.out_planes) {
+          *reinterpret_cast<f32x4*>(g.C + (long)m * g.ldc + n) = v;
+        } else {
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+            f16x2v h2, t2;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              _Float16 hq, tq;
+              h2_split(v[2 * pr + q], H2_ACT_SCALE, hq, tq, bad);   // as split2h_kernel: bit-identical planes
+              h2[q] = hq;
+              t2[q] = tq;
+            }
+            hw[g4][pr] = __builtin_bit_cast(unsigned, h2);
+            tw[g4][pr] = __builtin_bit_cast(unsigned, t2);
+          }
+        }
+      }
+      if (g.out_planes) {
+        // consumer plane element (m, k = n): ((m / 256) * (N / 32) + n / 32) * 256 * 32 + (m % 256) * 32 + n % 32
+        const long blk = ((long)(m0 / HM) * (g.N / HK) + (n0 + wn * 128 + jn * 32) / HK) * (HM * HK) + (long)(wm * 128 + i * 32 + l31) * HK;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int keep = 2 * j + hi, give = 2 * j + 1 - hi;
+          unsigned rh[2], rt[2];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            rh[q] = (unsigned)__shfl_xor((int)hw[give][q], 32, 64);
+            rt[q] = (unsigned)__shfl_xor((int)tw[give][q], 32, 64);
+          }
+          typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+          const u32x4v oh = hi ? u32x4v{rh[0], rh[1], hw[keep][0], hw[keep][1]} : u32x4v{hw[keep][0], hw[keep][1], rh[0], rh[1]};
+          const u32x4v ot = hi ? u32x4v{rt[0], rt[1], tw[keep][0], tw[keep][1]} : u32x4v{tw[keep][0], tw[keep][1], rt[0], rt[1]};
+          unsigned short* o = g.out_planes + blk + 16 * j + 8 * hi;
+          *reinterpret_cast<u32x4v*>(o) = oh;
+          *reinterpret_cast<u32x4v*>(o + g.out_plane) = ot;
+        }
+        if (bad && g.range_flag) *g.range_flag = 1;
+      }
+    }
+  }
+}
+
 // Tile choice (tn = 0).  Two kernels cover every row count: 256 x 256 tiles (one 8-wave workgroup per CU; ~15 % fewer operand bytes
 // and barriers per flop) and 128 x 128 tiles (two 4-wave workgroups per CU) -- measured on MI355X over M = 384 .. 31 616 on the four
 // NAR shapes (tools/gemm_short_rows.py, profiles/r03_gemm_tiles.log) the 128 x 128 tile is never slower than 256 x 128, and which of
 // the two wins is a matter of how the tile count quantises onto 256 CUs.  Cost model in units u of one 128 x 128 tile's work on a CU
 // (fits every measured point within a few percent): a round of 256 x 256 tiles costs 4 u; the 128-row kernel runs two tiles per CU
 // in 2.3 u, a lone one in 1.3 u.  All shapes give bit-identical sums (the per-element accumulation order does not depend on the tile).
-// tn = 128 / 256 / -128: forced (256 x 128 / 256 x 256 / 128 x 128; benchmarks).
+// tn = 128 / 256 / -128: forced (256 x 128 / 256 x 256 on the 8-wave kernel / 128 x 128; benchmarks); 257: 256 x 256 on the 4-wave kernel.
 void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s, int tn) {
   int tm = HM;
+  const int tn_in = tn == 257 ? 0 : tn;          // 257: 256 x 256 tiles forced ON THE FOUR-WAVE KERNEL (benchmarks)
+  if (tn == 257) tn = 256;
   if (tn == 0) {
     const long mt256 = (g.M + 255) / 256, mt128 = (g.M + 127) / 128;
     const long t128 = mt128 * ((g.N + 127) / 128);
@@ -417,7 +632,11 @@ void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s, int tn) {
   if (tn == 256 && prio == 2) { hipLaunchKernelGGL((gemm_f16x2_kernel<256, 256, 2, 2>), dim3(tiles), dim3(512), 0, s, g); return; }
   if (tn == 256 && prio == 0) { hipLaunchKernelGGL((gemm_f16x2_kernel<256, 256, 2, 0>), dim3(tiles), dim3(512), 0, s, g); return; }
 #endif
-  if (tn == 256) hipLaunchKernelGGL((gemm_f16x2_kernel<256, 256, 2, VX_GEMM_PRIO>), dim3(tiles), dim3(512), 0, s, g);
+  // 256 x 256 tiles: four waves of 128 x 128 (round 5) unless forced back (tn = 256 from a benchmark, VX_GEMM_W128=0) or K is one tile
+  static const bool w128 = [] { const char* e = getenv("VX_GEMM_W128"); return !(e && e[0] == '0'); }();
+  if (tn == 256 && tn_in != 256 && w128 && g.K >= 2 * HK && g.N % 256 == 0)
+    hipLaunchKernelGGL(gemm_f16x2_w128_kernel, dim3(tiles), dim3(256), 0, s, g);
+  else if (tn == 256) hipLaunchKernelGGL((gemm_f16x2_kernel<256, 256, 2, VX_GEMM_PRIO>), dim3(tiles), dim3(512), 0, s, g);
   else if (tm == 128 && tiles <= 256 && !two_stage)      // at most one workgroup per CU: four LDS stages, requests three K tiles ahead
     hipLaunchKernelGGL((gemm_f16x2_kernel<128, 128, 4>), dim3(tiles), dim3(256), 0, s, g);
   else if (tm == 128) hipLaunchKernelGGL((gemm_f16x2_kernel<128, 128>), dim3(tiles), dim3(256), 0, s, g);
