@@ -306,45 +306,70 @@ __global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_f32_dma_kernel
     mfmas(a1, b1);
   }
 
-  // epilogue: as gemm_f32_kernel (a lane owns one output row and 4-element runs of consecutive n)
+  // epilogue: gemm_f32_kernel's arithmetic (a lane owns one output row and 4-element runs of consecutive n), but no load -> wait ->
+  // use chain per 4 columns (two waves per SIMD hide little of it; the f16x2 kernels taught the lesson, profiles/
+  // r05_gemm_w128_workload_ab.log): the tile's bias / column-scale values go through the now idle LDS once, and the residual vectors
+  // of block (i, jn + 1) are requested before block (i, jn) is processed.
+  const bool has_bias = g.bias != nullptr, has_cs = g.colscale != nullptr, has_res = g.resid != nullptr;
+  float* const lbias = reinterpret_cast<float*>(lds);
+  float* const lcs = lbias + TN;
+  __syncthreads();                                   // every wave is past its last fragment reads: the stages are free
+  if (tid < TN / 4) {
+    const int n = n0 + tid * 4;                      // N % 4 == 0: a float4 is all in or all out
+    if (has_bias && n < g.N) *reinterpret_cast<f32x4*>(lbias + tid * 4) = *reinterpret_cast<const f32x4*>(g.bias + n);
+    if (has_cs && n < g.N) *reinterpret_cast<f32x4*>(lcs + tid * 4) = *reinterpret_cast<const f32x4*>(g.colscale + n);
+  }
+  __syncthreads();
+  auto load_rr = [&](int t, f32x4 (&rr)[4]) {       // block t = NJ i + jn
+    const int i = t / NJ, jn = t % NJ;
+    int m = m0 + wm * 64 + i * 32 + l31;
+    m = m < g.M ? m : g.M - 1;
+    const float* rp = g.resid + (long)m * g.ldr + n0 + wn * (TN / 2) + jn * 32 + 4 * hi;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int n = n0 + wn * (TN / 2) + jn * 32 + 8 * g4 + 4 * hi;
+      rr[g4] = n < g.N ? *reinterpret_cast<const f32x4*>(rp + 8 * g4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  f32x4 rrA[4], rrB[4];
+  if (has_res) load_rr(0, rrA);
+#pragma unroll
+  for (int t = 0; t < 2 * NJ; ++t) {
+    const int i = t / NJ, jn = t % NJ;
     const int m = m0 + wm * 64 + i * 32 + l31;
+    f32x4 (&rr)[4] = (t & 1) ? rrB : rrA;
+    if (has_res && t + 1 < 2 * NJ) load_rr(t + 1, (t & 1) ? rrA : rrB);
     if (m >= g.M) continue;
 #pragma unroll
-    for (int jn = 0; jn < NJ; ++jn) {
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int nl = wn * (TN / 2) + jn * 32 + 8 * g4 + 4 * hi, n = n0 + nl;
+      if (n >= g.N) continue;
+      f32x4 v = {acc[i][jn][4 * g4], acc[i][jn][4 * g4 + 1], acc[i][jn][4 * g4 + 2], acc[i][jn][4 * g4 + 3]};
+      if (has_bias) {
+        const f32x4 bi = *reinterpret_cast<const f32x4*>(lbias + nl);
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int n = n0 + wn * (TN / 2) + jn * 32 + 8 * g4 + 4 * hi;
-        if (n >= g.N) continue;
-        f32x4 v = {acc[i][jn][4 * g4], acc[i][jn][4 * g4 + 1], acc[i][jn][4 * g4 + 2], acc[i][jn][4 * g4 + 3]};
-        if (g.bias) {
-          const f32x4 bi = *reinterpret_cast<const f32x4*>(g.bias + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bi[e];
-        }
-        if (g.act == ACT_RELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (g.act == ACT_GELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-        } else if (g.act == ACT_ELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : expm1f(v[e]);
-        }
-        if (g.colscale) {
-          const f32x4 cs = *reinterpret_cast<const f32x4*>(g.colscale + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] * cs[e];
-        }
-        if (g.resid) {
-          const f32x4 rr = *reinterpret_cast<const f32x4*>(g.resid + (long)m * g.ldr + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = rr[e] + v[e];
-        }
-        *reinterpret_cast<f32x4*>(g.C + (long)m * g.ldc + n) = v;
+        for (int e = 0; e < 4; ++e) v[e] += bi[e];
       }
+      if (g.act == ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (g.act == ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+      } else if (g.act == ACT_ELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : expm1f(v[e]);
+      }
+      if (has_cs) {
+        const f32x4 cs = *reinterpret_cast<const f32x4*>(lcs + nl);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * cs[e];
+      }
+      if (has_res) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rr[g4][e] + v[e];
+      }
+      *reinterpret_cast<f32x4*>(g.C + (long)m * g.ldc + n) = v;
     }
   }
 }
