@@ -191,3 +191,15 @@ def test_fp32_dma_gemm_kernels_equal_the_register_staged_kernel_bit_for_bit():
         for kernel in (4, 5, 14, 0):                          # LDS-DMA 256 x 128 / 128 x 128 / 256 x 256 forced, the product's choice
             us, diff = eng.bench_gemm(M, N, K, kernel, 1)
             assert diff == 0.0, (M, N, K, kernel, diff)
+
+
+@pytest.mark.gpu
+def test_f16x2_four_wave_gemm_equals_the_eight_wave_kernel():
+    """round 5: the 4-wave (128 x 128 per wave) f16x2 GEMM accumulates every output element in the same order as the 8-wave kernel --
+    measured against the SAME fp32 reference the harness reports the same maximum difference, to the last bit, on the NAR shapes and on
+    ragged row counts (the product picks it for long row sets; kernel 15 forces it, 8 forces the 8-wave kernel)"""
+    import vallex_amd
+    eng = vallex_amd.Engine(num_layers=1, max_batch=1, max_text=8, max_prompt=8, max_new=8, with_vocos=False)
+    for (M, N, K) in ((31616, 3072, 1024), (31616, 1024, 4096), (2049, 1024, 1024), (300, 256, 64)):
+        d4, d8 = eng.bench_gemm(M, N, K, 15, 1)[1], eng.bench_gemm(M, N, K, 8, 1)[1]
+        assert d4 == d8 and d4 < 2e-3, (M, N, K, d4, d8)

@@ -175,3 +175,23 @@ def test_fp32_dma_gemm_tile_loop(asm):
         assert sum("vmcnt(0)" in w for w in waits) == 1 and sum(f"lgkmcnt({2 + nj})" in w for w in waits) >= 3, waits
         assert metadata(lines, name, "private_segment_fixed_size") == 0
         assert metadata(lines, name, "vgpr_count") <= (128 if nj == 2 else 256) and metadata(lines, name, "group_segment_fixed_size") == lds
+
+
+def test_f16x2_four_wave_gemm_steady_state_loop(asm):
+    """round 5: the 256 x 256 tile on four waves of 128 x 128 (the product's kernel for the long row sets): per K tile of 32 ONE
+    rendezvous between the two k16 steps, 96 MFMAs per wave (16 blocks x 3 products x 2 steps) on accumulators that stay in AGPRs (no
+    v_accvgpr move in the loop), 32 fragment reads (0.33 per MFMA) and the 16 LDS-DMA requests of tile kt + 2, each of them behind an
+    MFMA -- never two memory instructions back to back --, nothing spilled, one wave per SIMD"""
+    lines = asm("gemm_f16x2.hip")
+    body = kernel_body(lines, r"_ZN2vx22gemm_f16x2_w128_kernelE")
+    main = max(loops(body), key=lambda lp: count(lp, r"v_mfma"))
+    assert count(main, r"v_mfma_f32_32x32x16_f16") == 96
+    assert count(main, r"s_barrier") == 1
+    assert count(main, r"ds_read_b128") == 32 and count(main, r"global_load_lds_dwordx4") == 16
+    assert count(main, r"v_accvgpr") == 0 and count(body, r"scratch_") == 0
+    waits = [ln for ln in main if ln.startswith("s_waitcnt")]
+    assert len(waits) == 2 and sum("vmcnt(0)" in w for w in waits) == 1, waits          # the set of this step; the rendezvous
+    kinds = "".join("m" if ln.startswith("v_mfma") else "x" for ln in main if ln.startswith(("v_mfma", "ds_read_b128", "global_load_lds")))
+    assert "xxx" not in kinds                                      # at most a read + a request between two MFMAs
+    assert metadata(lines, "gemm_f16x2_w128_kernel", "private_segment_fixed_size") == 0
+    assert metadata(lines, "gemm_f16x2_w128_kernel", "vgpr_count") <= 512 and metadata(lines, "gemm_f16x2_w128_kernel", "group_segment_fixed_size") == 131072

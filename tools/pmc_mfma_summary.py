@@ -12,7 +12,7 @@ import sys
 
 # only the long (>= 200 us) kernels: GRBM_GUI_ACTIVE of a 7-36 us decode kernel includes the idle ramp around it (implied clocks of
 # 2.8-4.6 GHz), so a busy fraction relative to it means nothing there
-KERNELS = {"gemm_f16x2 (256x256 tiles)": "gemm_f16x2_kernel<256, 256", "attn_full_h2": "attn_full_h2_kernel",
+KERNELS = {"gemm_f16x2 (256x256 tiles, 4 waves of 128x128)": "gemm_f16x2_w128_kernel", "gemm_f16x2 (256x256 tiles, 8 waves of 64x128)": "gemm_f16x2_kernel<256, 256", "attn_full_h2": "attn_full_h2_kernel",
            "gemm_f32 register-staged (Vocos head, short row sets)": "gemm_f32_kernel",
            "gemm_f32 LDS-DMA 256 x 256 (every long projection with --arith f32)": "gemm_f32_dma_kernel<256, 256>",
            "gemm_f32 LDS-DMA 256 x 128 (long row sets, N % 256 != 0: Vocos)": "gemm_f32_dma_kernel<256, 128>",

@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 
 KERNELS = {  # json suffix -> (kernel-name substring, what the algorithmic bytes of one launch are)
     "dec_attn": "dec_attn_kernel",
-    "gemm_f16x2": "gemm_f16x2_kernel",
+    "gemm_f16x2": "gemm_f16x2_",            # gemm_f16x2_w128_kernel (long row sets) + gemm_f16x2_kernel<...> (short ones), launch-weighted
     "skinny_gemm": "skinny_gemm_kernel",
     "skinny16": "skinny16_relu_pack_kernel",
     "attn_full_x3": "attn_full_x3_kernel",
