@@ -21,6 +21,8 @@
 #   evidence RND [ARITH]           rocprofv3 --kernel-trace summary + a separate --pmc FETCH_SIZE pass of `bench.py --steps 1 [--arith ARITH]`
 #   mfma RND [ARITH]               three more separate --pmc passes (MFMA / VALU busy, issue stalls) of the same command
 #   gaps LABEL [bench.py args]     kernel trace of a short bench run -> per-kernel duration + gap to the next launch (tools/rocpd_gaps.py)
+#   by_shape LABEL [ENV=V ...]    kernel trace of one default bench pass, per-kernel stats split by grid size (tools/rocpd_by_grid.py): the launches
+#                                  of one GEMM kernel over different shapes come out as separate rows -> <tag>_by_shape_LABEL.csv
 #   py SCRIPT [args]               python tools/SCRIPT args  (the kernel micro-benchmarks: gemm_ab.py, attn_ab.py, step_timeline.py ...)
 R="${GRAFT_REPO_ROOT:-$PWD}"; cd "$R" || exit 1
 mkdir -p gpurun_out
@@ -197,6 +199,14 @@ step_gaps() {
     [ -n "$DB" ] && python "$R/tools/rocpd_gaps.py" "$DB" > "$R/gpurun_out/${TAG}_gaps_${label}.csv" && head -30 "$R/gpurun_out/${TAG}_gaps_${label}.csv"
     [ -n "$DB" ] && python "$R/tools/rocpd_summary.py" "$DB" > "$R/gpurun_out/${TAG}_gaps_${label}_kernel_stats.csv"
     rm -rf "$R/gpurun_out/prof_g" )
+}
+step_by_shape() {
+  local label="$1"; shift
+  ( cd /tmp && export TMPDIR=/tmp
+    env "$@" timeout 400 rocprofv3 --kernel-trace -d "$R/gpurun_out/prof_s" -o s -- python "$R/bench.py" --steps 1 --warmup 0 $BQ > "$R/gpurun_out/${TAG}_by_shape_${label}.log" 2>&1; echo "trace rc=$?"
+    DB=$(find "$R/gpurun_out/prof_s" -name '*.db' | head -1)
+    [ -n "$DB" ] && python "$R/tools/rocpd_by_grid.py" "$DB" gemm_ attn_full > "$R/gpurun_out/${TAG}_by_shape_${label}.csv" && cat "$R/gpurun_out/${TAG}_by_shape_${label}.csv"
+    rm -rf "$R/gpurun_out/prof_s" )
 }
 step_py() { local s="$1"; shift; timeout 600 python tools/$s "$@" 2>&1 | tee gpurun_out/${TAG}_$(basename $s .py).log | tail -60; }
 
