@@ -151,7 +151,8 @@ int vx_ar_step(vx_ctx* ctx, const int32_t* tokens);
 /* NAR stages only (models/vallex.py:600-686): codes0 [batch][codes0_stride] first-codebook ids, lens [batch] */
 int vx_nar(vx_ctx* ctx, const vx_batch* b, const int32_t* codes0, int32_t codes0_stride, const int32_t* lens,
            int64_t* out_codes, int32_t out_stride);
-/* copy a named debug buffer to the host (needs cfg.debug_taps); returns the number of floats copied or < 0 */
+/* copy a named debug buffer (needs cfg.debug_taps) -- or, when no tap has that name, a tensor exactly as vx_load_tensor stored it
+ * (read-back check of an upload) -- to the host; returns the number of floats copied or < 0 */
 int64_t vx_read_tap(vx_ctx* ctx, const char* name, float* dst, int64_t max_floats);
 
 /* counters of the last vx_infer: AR steps run, generated frames, AR / NAR wall milliseconds (stream-synchronised) */

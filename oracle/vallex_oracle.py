@@ -271,7 +271,7 @@ class VallexOracle:
 
     # ---- NAR (models/vallex.py:600-686, prefix_mode 1) ----------------------
     def nar_generate(self, text, prompts, codes0: Sequence[int], enroll, prompt_language, text_language,
-                     taps=None) -> np.ndarray:
+                     taps=None, stage_logits: Optional[list] = None) -> np.ndarray:
         Tp = prompts.shape[0]
         T = len(codes0)
         y = torch.cat([prompts[:, 0], torch.tensor(list(codes0), dtype=torch.long)])
@@ -291,6 +291,8 @@ class VallexOracle:
             logits = F.linear(dec[S + Tp:], self.w[f"nar_predict_layers.{i}.weight"])
             if taps is not None:
                 taps.setdefault("nar_logits", []).append(logits.clone())
+            if stage_logits is not None:                                     # bench.py's parity block: the decision margins
+                stage_logits.append(logits)
             samples = torch.argmax(logits, dim=-1)
             codes.append(samples)
             if i < synth.NUM_QUANTIZERS - 2:

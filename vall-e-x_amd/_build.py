@@ -9,6 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libvallex_hip.so")
+PREFLIGHT = os.path.join(CSRC, "vx_preflight.bin")      # library-free box check (csrc/preflight.hip, vall-e-x_amd/_preflight.py)
 SOURCES = ["gemm_f32.hip", "gemm_f16x2.hip", "gemm_bf16x3.hip", "gemm_bf16x3_dma.hip", "rows.hip", "attn_full.hip", "attn_full_x3.hip", "attn_full_h2.hip", "decode.hip", "vocos.hip", "encodec.hip", "engine.hip", "weights.hip", "vocoders.hip", "bench_harness.hip"]
 HEADERS = ["vx_common.h"]                    # every translation unit
 # the engine's translation units (host code: context, drivers, C ABI) also see the internal context header and the public ABI
@@ -109,6 +110,23 @@ def build_library(force: bool = False, verbose: bool = False, dev: bool = False,
     return lib
 
 
+def build_preflight(force: bool = False) -> str:
+    """The stand-alone pre-flight executable (no libvallex, no torch): one translation unit, linked against the system HIP runtime."""
+    force = force or os.environ.get("VX_FORCE_BUILD", "") == "1"
+    src = os.path.join(CSRC, "preflight.hip")
+    fl = ["--offload-arch=gfx950", "-O2", "-std=c++17"]
+    if force or _stale(PREFLIGHT, [src], fl):
+        cmd = [_hipcc()] + fl + [src, "-o", PREFLIGHT]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        _stamp(PREFLIGHT, [src], fl)
+        print("[build] vx_preflight.bin compiled for gfx950", flush=True)
+    return PREFLIGHT
+
+
 if __name__ == "__main__":
     var = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--variant=")]
     print(build_library(force="--force" in sys.argv, verbose=True, dev="--dev" in sys.argv, variant=var[0] if var else ""))
+    if "--dev" not in sys.argv and not var:
+        print(build_preflight(force="--force" in sys.argv))

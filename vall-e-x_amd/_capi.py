@@ -78,6 +78,12 @@ def load_library() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise OSError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # ONE HIP runtime per process.  torch bundles its own libamdhip64 / libhsa-runtime64 (same soname as /opt/rocm's): dlopen'ing
+    # this library BEFORE torch binds it to the system runtime and the later `import torch` maps a second copy of the HIP runtime
+    # and of ROCr into the process (two runtimes driving one GPU address space).  The API mirrors import torch anyway (the
+    # reference's signatures hand tensors in and out), so import it here, first: the library then resolves libamdhip64.so.7 to
+    # the copy that is already loaded.  A C client (examples/*.c) has no torch and runs on the system runtime alone.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     if LIB_OVERRIDDEN:
         import sys

@@ -37,7 +37,7 @@ int vx_prof_reset(vx_ctx* c) {
 int vx_prof_get(vx_ctx* c, int32_t which, double* total_ms, int64_t* launches, double* algo_bytes) {
   if (!c || which < 0 || which > 5) return VX_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  SYNC();
   ProfClass& p = c->prof[which];
   double tot = 0;
   for (size_t i = 0; i + 1 < p.used; i += 2) {
@@ -74,13 +74,13 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
     if (c->fuse_out && c->nsplit == 1) bytes += (double)D_MODEL * D_MODEL * 4.0;     // + W_o, streamed once (fused out_proj)
     // the replay's contexts go into the per-slot view dec_attn reads (the row order of the last prefill is kept)
     std::vector<int> meta(4 * nb);
-    HIPCHK(hipMemcpyAsync(meta.data(), c->slot_meta, meta.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    D2H(meta.data(), c->slot_meta, meta.size() * sizeof(int));
+    SYNC();
     for (int y = 0; y < nb; ++y) { meta[4 * y + 1] = ctx[meta[4 * y]]; meta[4 * y + 2] = 1; }
-    HIPCHK(hipMemcpyAsync(c->slot_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->ctx_len, ctx.data(), nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->active, one.data(), nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    H2D(c->slot_meta, meta.data(), meta.size() * sizeof(int));
+    H2D(c->ctx_len, ctx.data(), nb * sizeof(int));
+    H2D(c->active, one.data(), nb * sizeof(int));
+    SYNC();
     // rotate over the layers' KV arenas like the real step does: the working set (NL x ~178 MB at batch 32) is far beyond
     // the 256 MiB Infinity Cache, so no launch is served from it
     const size_t cache_layer = (size_t)c->mbr * N_HEAD * c->Tmax * D_HEAD;
@@ -142,12 +142,12 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
     HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
     (void)hipGraphDestroy(g);
     for (int w = 0; w < 3; ++w) HIPCHK(hipGraphLaunch(ge, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SYNC();
     dev_clear_stamps();
     HIPCHK(hipEventRecord(e0, c->stream));
     for (int r = 0; r < reps; ++r) HIPCHK(hipGraphLaunch(ge, c->stream));
     HIPCHK(hipEventRecord(e1, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    SYNC();
     (void)hipGraphExecDestroy(ge);
     launches = reps;
     bytes = 0;
@@ -217,9 +217,9 @@ static int bench_gemm_impl(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t k
       }
     };
     fill((size_t)M * K);
-    TRY(hipMemcpy(A, h.data(), (size_t)M * K * 4, hipMemcpyHostToDevice));
+    H2D(A, h.data(), (size_t)M * K * 4);
     fill((size_t)N * K);
-    TRY(hipMemcpy(Wt, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice));
+    H2D(Wt, h.data(), (size_t)N * K * 4);
   }
   GemmArgs g0{};
   g0.A = A; g0.lda = K; g0.W = Wt; g0.ldw = K; g0.C = C0; g0.ldc = N; g0.M = M; g0.N = N; g0.K = K; g0.act = ACT_NONE;
@@ -270,7 +270,7 @@ static int bench_gemm_impl(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t k
   if (clock_mhz || (want_clock && want_clock[0] == '1')) {
     TRY(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
     TRY(hipMalloc((void**)&d_clk, 16));
-    TRY(hipStreamSynchronize(c->stream));
+    SYNC();
   }
   hipEvent_t e0, e1;
   TRY(hipEventCreate(&e0));
@@ -289,7 +289,7 @@ static int bench_gemm_impl(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t k
   if (s2) {
     unsigned long long hclk[2] = {0, 0};
     TRY(hipStreamSynchronize(s2));
-    TRY(hipMemcpy(hclk, d_clk, 16, hipMemcpyDeviceToHost));
+    D2H(hclk, d_clk, 16); SYNC();
     const double mhz = hclk[1] ? (double)hclk[0] / ((double)hclk[1] / 100.0) : 0.0;
     if (clock_mhz) *clock_mhz = mhz;
     else
@@ -300,13 +300,13 @@ static int bench_gemm_impl(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t k
   }
   const int rows = std::min(M, 256);
   std::vector<float> h0((size_t)rows * N), h1((size_t)rows * N);
-  TRY(hipMemcpy(h0.data(), C0, h0.size() * 4, hipMemcpyDeviceToHost));
-  TRY(hipMemcpy(h1.data(), C1, h1.size() * 4, hipMemcpyDeviceToHost));
+  D2H(h0.data(), C0, h0.size() * 4); SYNC();
+  D2H(h1.data(), C1, h1.size() * 4); SYNC();
   // also the LAST rows (tile tails)
   double md = 0;
   for (size_t i = 0; i < h0.size(); ++i) md = std::max(md, (double)fabsf(h0[i] - h1[i]));
-  TRY(hipMemcpy(h0.data(), C0 + (size_t)(M - rows) * N, h0.size() * 4, hipMemcpyDeviceToHost));
-  TRY(hipMemcpy(h1.data(), C1 + (size_t)(M - rows) * N, h1.size() * 4, hipMemcpyDeviceToHost));
+  D2H(h0.data(), C0 + (size_t)(M - rows) * N, h0.size() * 4); SYNC();
+  D2H(h1.data(), C1 + (size_t)(M - rows) * N, h1.size() * 4); SYNC();
   for (size_t i = 0; i < h0.size(); ++i) md = std::max(md, (double)fabsf(h0[i] - h1[i]));
   *max_abs_diff = md;
 #undef TRY
@@ -350,10 +350,10 @@ int vx_bench_attn(vx_ctx* c, int32_t batch, int32_t len, int32_t causal, int32_t
     for (auto& v : h) { st = st * 6364136223846793005ull + 1442695040888963407ull; v = (float)((st >> 40) & 0xFFFFFF) / 8388608.0f - 1.0f; }
     // Q columns x4: scores of a few units instead of ~0.3, so the softmax is not nearly uniform
     for (long r = 0; r < M; ++r) for (int k = 0; k < D_MODEL; ++k) h[(size_t)r * 3 * D_MODEL + k] *= 4.0f;
-    TRY(hipMemcpy(qkv, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    H2D(qkv, h.data(), h.size() * 4);
     std::vector<int> m(3 * batch);
     for (int i = 0; i < batch; ++i) { m[i] = i * len; m[batch + i] = len; m[2 * batch + i] = len / 3; }
-    TRY(hipMemcpy(meta, m.data(), m.size() * 4, hipMemcpyHostToDevice));
+    H2D(meta, m.data(), m.size() * 4);
   }
   const int* pre = causal ? meta + 2 * batch : nullptr;
   auto run = [&]() {
@@ -384,10 +384,10 @@ int vx_bench_attn(vx_ctx* c, int32_t batch, int32_t len, int32_t causal, int32_t
     *max_diff = -1.0;
     if (variant == 0 || variant == 10 || (variant >= 20 && variant <= 23)) {
       launch_attn_full(qkv, ref, meta, meta + batch, pre, batch, len, c->stream);
-      TRY(hipStreamSynchronize(c->stream));
+      SYNC();
       std::vector<float> ho((size_t)M * D_MODEL), hr((size_t)M * D_MODEL);
-      TRY(hipMemcpy(ho.data(), out, ho.size() * 4, hipMemcpyDeviceToHost));
-      TRY(hipMemcpy(hr.data(), ref, hr.size() * 4, hipMemcpyDeviceToHost));
+      D2H(ho.data(), out, ho.size() * 4); SYNC();
+      D2H(hr.data(), ref, hr.size() * 4); SYNC();
       double md = 0;
       for (size_t i = 0; i < ho.size(); ++i) {
         const double d = std::fabs((double)ho[i] - (double)hr[i]);

@@ -4,7 +4,9 @@
 #include "engine_ctx.h"
 
 namespace {
-std::string g_create_err;
+// the message of a failed vx_create (no context to hang it on): per thread, contexts are created from several host threads
+// (bench.py --contexts) and vx_last_error(NULL) must not read a string another thread is assigning
+thread_local std::string g_create_err;
 }  // namespace
 
 namespace vxe {
@@ -14,12 +16,60 @@ const float* W(vx_ctx* c, const std::string& name) {
   return it == c->w.end() ? nullptr : it->second.d;
 }
 
+// ---- pinned transfer ring (engine_ctx.h: PinRing) ----------------------------------------------------------
+static int ring_slot(vx_ctx* c, size_t n, char** slot) {
+  PinRing& r = c->ring;
+  if (!r.base) FAIL(VX_ESTATE, "the context has no pinned transfer ring");
+  const size_t a = (n + 255) & ~(size_t)255;
+  if (r.head + a > r.cap) if (int e = xfer_sync(c)) return e;
+  *slot = r.base + r.head;
+  r.head += a;
+  return VX_OK;
+}
+
+int xfer_h2d(vx_ctx* c, void* dst_dev, const void* src_host, size_t bytes) {
+  const char* s = static_cast<const char*>(src_host);
+  char* d = static_cast<char*>(dst_dev);
+  while (bytes) {
+    const size_t n = std::min(bytes, XFER_CHUNK);
+    char* slot = nullptr;
+    if (int e = ring_slot(c, n, &slot)) return e;
+    memcpy(slot, s, n);
+    HIPCHK(hipMemcpyAsync(d, slot, n, hipMemcpyHostToDevice, c->stream));
+    s += n; d += n; bytes -= n;
+  }
+  return VX_OK;
+}
+
+int xfer_d2h(vx_ctx* c, void* dst_host, const void* src_dev, size_t bytes) {
+  char* d = static_cast<char*>(dst_host);
+  const char* s = static_cast<const char*>(src_dev);
+  while (bytes) {
+    const size_t n = std::min(bytes, XFER_CHUNK);
+    char* slot = nullptr;
+    if (int e = ring_slot(c, n, &slot)) return e;
+    HIPCHK(hipMemcpyAsync(slot, s, n, hipMemcpyDeviceToHost, c->stream));
+    c->ring.pend.push_back({d, slot, n});
+    s += n; d += n; bytes -= n;
+  }
+  return VX_OK;
+}
+
+int xfer_sync(vx_ctx* c) {
+  const hipError_t e = hipStreamSynchronize(c->stream);
+  PinRing& r = c->ring;
+  if (e == hipSuccess)
+    for (const PinRing::Pend& p : r.pend) memcpy(p.dst, p.src, p.n);
+  r.pend.clear();
+  r.head = 0;
+  HIPCHK(e);
+  return VX_OK;
+}
+
 // ---- int metadata upload ---------------------------------------------------------------------------------
 int upload_meta(vx_ctx* c) {
   if ((long)c->hmeta.size() > c->imeta_cap) FAIL(VX_EINVAL, "row metadata overflow (%zu > %ld)", c->hmeta.size(), c->imeta_cap);
-  HIPCHK(hipMemcpyAsync(c->imeta, c->hmeta.data(), c->hmeta.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  // the host vector is reused by the next call: make the copy complete first
-  HIPCHK(hipStreamSynchronize(c->stream));
+  H2D(c->imeta, c->hmeta.data(), c->hmeta.size() * sizeof(int));      // staged: the host vector is free for the next call
   return VX_OK;
 }
 
@@ -170,8 +220,8 @@ int take_range_flag(vx_ctx* c, bool* raised) {
   *raised = false;
   if (!range_guarded(c)) return VX_OK;
   int flag = 0;
-  HIPCHK(hipMemcpyAsync(&flag, c->range_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  D2H(&flag, c->range_flag, sizeof(int));
+  SYNC();
   if (flag) HIPCHK(hipMemsetAsync(c->range_flag, 0, sizeof(int), c->stream));
   *raised = flag != 0;
   return VX_OK;
@@ -279,7 +329,7 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
   HIPCHK(hipMemcpyAsync(c->text_len, mb.dev(o_sS), ib, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->slot_meta, mb.dev(o_meta), 4 * ib, hipMemcpyDeviceToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->slot_of, mb.dev(o_slot), ib, hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(c->n_active, &nrows, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  H2D(c->n_active, &nrows, sizeof(int));
   c->cur_batch = nrows;
   // enough (row, head, split) 8-wave workgroups to put >= 2 on every CU; one split (no combine launch) from 32 rows up
   c->nsplit = std::max(1, std::min(16, 512 / (nrows * N_HEAD)));
@@ -537,13 +587,13 @@ int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int 
     std::vector<float> u((size_t)steps * nb);
     for (long t = 0; t < steps; ++t)
       for (int i = 0; i < nb; ++i) u[t * nb + i] = s->uniforms[t * ub + r0 + i];
-    HIPCHK(hipMemcpyAsync(c->d_uniforms, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    H2D(c->d_uniforms, u.data(), u.size() * sizeof(float));
+    SYNC();
   }
   // the seed of the counter-based sampler lives in a device word: a new seed per call (the reference's contract, every call
   // draws from torch's generator) does not change the captured step graph
   const unsigned long long seed = s->seed;
-  HIPCHK(hipMemcpyAsync(c->seed_dev, &seed, sizeof seed, hipMemcpyHostToDevice, c->stream));
+  H2D(c->seed_dev, &seed, sizeof seed);
   SampleArgs sa = make_sample_args(c, s, 1, nullptr);
   std::vector<int> act(nb);
   bool any = true, raised = false;
@@ -554,9 +604,9 @@ int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int 
     HIPCHK(hipMemsetAsync(c->sum_logp, 0, MB * sizeof(float), c->stream));
     LAUNCH(launch_dec_sample(sa, c->stream));
     if (int e = launch_status(c)) return e;
-    HIPCHK(hipMemcpyAsync(act.data(), c->active, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    if (range_guarded(c) && !direct_f32) HIPCHK(hipMemcpyAsync(&flag, c->range_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    D2H(act.data(), c->active, nb * sizeof(int));
+    if (range_guarded(c) && !direct_f32) D2H(&flag, c->range_flag, sizeof(int));
+    SYNC();
     raised = flag != 0;
     any = std::any_of(act.begin(), act.end(), [](int v) { return v != 0; });
     return VX_OK;
@@ -589,16 +639,16 @@ int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int 
     if (int e = ar_step_run(c, &sa, sig, n)) return e;
     steps += n;
     if (steps % sync_every == 0) {
-      HIPCHK(hipMemcpyAsync(act.data(), c->active, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
+      D2H(act.data(), c->active, nb * sizeof(int));
+      SYNC();
       any = std::any_of(act.begin(), act.end(), [](int v) { return v != 0; });
     }
   }
   n_gen.resize(nb);
   gen.resize((size_t)nb * c->gen_stride);
-  HIPCHK(hipMemcpyAsync(n_gen.data(), c->n_gen, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(gen.data(), c->gen, gen.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  D2H(n_gen.data(), c->n_gen, nb * sizeof(int));
+  D2H(gen.data(), c->gen, gen.size() * sizeof(int));
+  SYNC();
   c->st_steps += steps;
   if (c->prof_on) {
     // algorithmic KV bytes: every decode step of an active row reads ctx rows of K and V in all layers
@@ -711,8 +761,8 @@ int nar_generate_once(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::v
       // this context has left the fp16 range in a NAR phase before: look at the flag behind stage 0 already, so that an
       // out-of-range model does not pay six more f16x2 stages before the fp32 re-run (costs one host sync; never in the common case)
       int early = 0;
-      HIPCHK(hipMemcpyAsync(&early, c->range_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
+      D2H(&early, c->range_flag, sizeof(int));
+      SYNC();
       if (early) {
         HIPCHK(hipMemsetAsync(c->range_flag, 0, sizeof(int), c->stream));
         return VX_RETRY_F32;
@@ -723,11 +773,10 @@ int nar_generate_once(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::v
       launch_embed_accum(c->fyemb, mb.dev(o_gy), W(c, nm), samples, (int)sumT, c->stream);
     }
   }
-  HIPCHK(hipMemcpyAsync(out_codes.data(), c->imeta + o_samples, out_codes.size() * sizeof(int), hipMemcpyDeviceToHost,
-                        c->stream));
+  D2H(out_codes.data(), c->imeta + o_samples, out_codes.size() * sizeof(int));
   int flag = 0;                        // the range flag rides on the sync that brings the ids back
-  if (range_guarded(c)) HIPCHK(hipMemcpyAsync(&flag, c->range_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  if (range_guarded(c)) D2H(&flag, c->range_flag, sizeof(int));
+  SYNC();
   if (flag) {
     HIPCHK(hipMemsetAsync(c->range_flag, 0, sizeof(int), c->stream));
     return VX_RETRY_F32;
@@ -802,6 +851,19 @@ int vx_create(int device_id, const vx_config* cfg, vx_ctx** out) {
       (void)hipStreamDestroy(c->stream);
       return fail(e, "hipEventCreate");
     }
+  // the pinned transfer ring (engine_ctx.h): 64 MiB unless VX_PIN_MB says otherwise (>= 2 chunks)
+  {
+    size_t mb = 64;
+    if (const char* ev = getenv("VX_PIN_MB")) mb = (size_t)std::max(16, std::min(1024, atoi(ev)));
+    void* q = nullptr;
+    if ((e = hipHostMalloc(&q, mb << 20, hipHostMallocDefault)) != hipSuccess) {
+      for (auto& e2 : c->ev_t) if (e2) (void)hipEventDestroy(e2);
+      (void)hipStreamDestroy(c->stream);
+      return fail(e, "hipHostMalloc (pinned transfer ring)");
+    }
+    c->ring.base = static_cast<char*>(q);
+    c->ring.cap = mb << 20;
+  }
   *out = c;
   return VX_OK;
 }
@@ -817,13 +879,14 @@ void vx_destroy(vx_ctx* c) {
   for (void* p : c->allocs) (void)hipFree(p);
   for (auto& kv : c->w) (void)hipFree(kv.second.d);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->ring.base) (void)hipHostFree(c->ring.base);
   delete c;
 }
 
 int vx_synchronize(vx_ctx* c) {
   if (!c) return VX_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  SYNC();
   return VX_OK;
 }
 
@@ -844,7 +907,7 @@ int vx_ar_prefill(vx_ctx* c, const vx_batch* b) {
     F32Scope f32(c);
     if (int e = ar_prefill(c, b, 0, b->batch)) return e;
   }
-  HIPCHK(hipStreamSynchronize(c->stream));                 // the seam returns with the prefill complete in every mode
+  SYNC();                 // the seam returns with the prefill complete in every mode
   HIPCHK(hipGetLastError());
   return VX_OK;
 }
@@ -856,8 +919,8 @@ int vx_ar_logits(vx_ctx* c, float* out) {
   SampleArgs sa = make_sample_args(c, nullptr, 0, c->d_logits);
   LAUNCH(launch_dec_sample(sa, c->stream));
   if (int e = launch_status(c)) return e;
-  HIPCHK(hipMemcpyAsync(out, c->d_logits, (size_t)c->cur_batch * AR_LOGITS * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  D2H(out, c->d_logits, (size_t)c->cur_batch * AR_LOGITS * sizeof(float));
+  SYNC();
   return VX_OK;
 }
 
@@ -865,11 +928,11 @@ int vx_ar_step(vx_ctx* c, const int32_t* tokens) {
   if (!c || !tokens) return VX_EINVAL;
   if (c->cur_batch <= 0) FAIL(VX_ESTATE, "no prefill has run");
   HIPCHK(hipSetDevice(c->dev));
-  HIPCHK(hipMemcpyAsync(c->force_tok, tokens, c->cur_batch * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  H2D(c->force_tok, tokens, c->cur_batch * sizeof(int));
   launch_dec_force_token(c->force_tok, c->cur_tok, c->cur_pos, c->ctx_len, c->n_gen, c->gen, c->gen_stride, c->active,
                          c->cur_batch, c->slot_meta, c->slot_of, c->stream);
   if (int e = ar_step_run(c, nullptr, "")) return e;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  SYNC();
   HIPCHK(hipGetLastError());
   return VX_OK;
 }
@@ -928,7 +991,7 @@ int vx_infer(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int64_t* out_co
     std::vector<int> n_gen, gen, oc;
     if (int e = ar_generate(c, b, s, 0, 1, n_gen, gen, N)) return e;     // ONE prefill, N decode rows
     std::vector<float> slp(N);
-    HIPCHK(hipMemcpy(slp.data(), c->sum_logp, N * sizeof(float), hipMemcpyDeviceToHost));
+    D2H(slp.data(), c->sum_logp, N * sizeof(float)); SYNC();
     int best = 0, worst = 0;
     double bv = 0, wv = 0;
     for (int i = 0; i < N; ++i) {
@@ -987,11 +1050,15 @@ int vx_infer(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int64_t* out_co
 int64_t vx_read_tap(vx_ctx* c, const char* name, float* dst, int64_t max_floats) {
   if (!c || !name || !dst) return VX_EINVAL;
   auto it = c->taps.find(name);
-  if (it == c->taps.end()) FAIL(VX_ENOTFOUND, "no tap '%s'", name);
+  if (it == c->taps.end()) {
+    // not a tap: a tensor as vx_load_tensor stored it (read-back check of an upload, tools/verify_checkpoint.py)
+    it = c->w.find(name);
+    if (it == c->w.end()) FAIL(VX_ENOTFOUND, "no tap or loaded tensor '%s'", name);
+  }
   const int64_t n = std::min<int64_t>((int64_t)it->second.n, max_floats);
   HIPCHK(hipSetDevice(c->dev));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  HIPCHK(hipMemcpy(dst, it->second.d, n * sizeof(float), hipMemcpyDeviceToHost));
+  SYNC();
+  D2H(dst, it->second.d, n * sizeof(float)); SYNC();
   return n;
 }
 

@@ -34,6 +34,20 @@ struct LayerW {
   unsigned short *in_w3 = nullptr, *out_w3 = nullptr, *l1_w3 = nullptr, *l2_w3 = nullptr;   // 3 bf16 planes [3][N][K]
 };
 
+// Host <-> device transfers.  Every byte that crosses the boundary goes through a context-owned PINNED ring (hipHostMalloc, one per
+// context = per GPU = per rank): a host source is copied into the ring and DMA'd from there, a host destination is filled from the
+// ring behind the next stream sync.  No call of the library hands a caller's (or its own) pageable pages to the runtime, so nothing
+// depends on the driver pinning user memory on the fly (the userptr path -- the one a box-level fault of round 5 died in, inside the
+// first weight upload, replacing load_state_dict + .to(device) of utils/generation.py:79-83).  Transfers larger than a chunk are cut
+// into chunks, so the CPU copy of chunk i + 1 overlaps the DMA of chunk i; the ring wraps by synchronising the stream.
+struct PinRing {
+  char* base = nullptr;
+  size_t cap = 0, head = 0;
+  struct Pend { void* dst; const char* src; size_t n; };
+  std::vector<Pend> pend;          // device -> host copies in flight: ring slot -> caller memory at the next xfer_sync
+};
+constexpr size_t XFER_CHUNK = 8u << 20;
+
 struct ProfClass {
   std::vector<hipEvent_t> ev;   // pairs
   size_t used = 0;
@@ -52,6 +66,7 @@ struct vx_ctx {
   vx_config cfg{};
   int dev = 0;
   hipStream_t stream = nullptr;
+  PinRing ring;                    // pinned staging of every host transfer (xfer_h2d / xfer_d2h / xfer_sync)
   hipEvent_t ev_t[3] = {nullptr, nullptr, nullptr};   // AR / NAR phase timing of vx_infer (created once, vx_create)
   std::string err;
   const char* launch_fail = nullptr;   // a launcher refused a configuration that is not compiled in (set by LAUNCH, read by the ABI call)
@@ -190,6 +205,13 @@ struct vx_ctx {
   } while (0)
 
 namespace vxe {
+
+int xfer_h2d(vx_ctx* c, void* dst_dev, const void* src_host, size_t bytes);    // asynchronous on c->stream; src is free on return
+int xfer_d2h(vx_ctx* c, void* dst_host, const void* src_dev, size_t bytes);    // dst is valid after the next xfer_sync
+int xfer_sync(vx_ctx* c);                                                      // stream sync + delivery of pending d2h + ring reset
+#define H2D(dst, src, bytes) do { if (int _e = xfer_h2d(c, (dst), (src), (bytes))) return _e; } while (0)
+#define D2H(dst, src, bytes) do { if (int _e = xfer_d2h(c, (dst), (src), (bytes))) return _e; } while (0)
+#define SYNC() do { if (int _e = xfer_sync(c)) return _e; } while (0)
 
 template <typename T>
 int dev_alloc(vx_ctx* c, T** p, size_t count, bool zero = true) {

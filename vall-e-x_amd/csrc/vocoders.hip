@@ -86,11 +86,9 @@ int vx_vocos_decode(vx_ctx* c, const int64_t* codes, int32_t codes_stride, const
     launch_overlap_add(c->vframes, NF, mb.dev(o_off), mb.dev(o_len), c->vc_win2, c->vaudio, 0, nj, maxT, st);
     for (int j = 0; j < nj; ++j) {
       const Job& jb = jobs[j0 + j];
-      HIPCHK(hipMemcpyAsync(audio + (long)jb.row * audio_stride + (long)jb.a * 320,
-                            c->vaudio + ((long)seq_off[j] + (jb.a - jb.lo)) * 320, (size_t)(jb.b - jb.a) * 320 * sizeof(float),
-                            hipMemcpyDeviceToHost, st));
+      D2H(audio + (long)jb.row * audio_stride + (long)jb.a * 320, c->vaudio + ((long)seq_off[j] + (jb.a - jb.lo)) * 320, (size_t)(jb.b - jb.a) * 320 * sizeof(float));
     }
-    HIPCHK(hipStreamSynchronize(st));
+    SYNC();
     HIPCHK(hipGetLastError());
     j0 = j1;
   }
@@ -183,9 +181,8 @@ int vx_encodec_decode(vx_ctx* c, const int64_t* codes, int32_t codes_stride, con
     launch_final_conv(cur, W(c, "encodec.decoder.15.weight"), W(c, "encodec.decoder.15.bias"), d_off, d_len, (int)R,
                       c->ec_audio, astride, nb, (long)maxT * R, st);
     for (int i = 0; i < nb; ++i)
-      HIPCHK(hipMemcpyAsync(audio + (long)(r0 + i) * audio_stride, c->ec_audio + (long)i * astride,
-                            (size_t)seq_len[i] * 320 * sizeof(float), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+      D2H(audio + (long)(r0 + i) * audio_stride, c->ec_audio + (long)i * astride, (size_t)seq_len[i] * 320 * sizeof(float));
+    SYNC();
     HIPCHK(hipGetLastError());
   }
   return VX_OK;
@@ -229,8 +226,7 @@ int vx_encodec_encode(vx_ctx* c, const float* wav, int64_t wav_stride, const int
     const int* d_len = mb.dev(o_len);
     // ---- convolutional stack, one sequence at a time (prompts are few and long; the arena is reused) ----
     for (int i = 0; i < nb; ++i) {
-      HIPCHK(hipMemcpyAsync(c->ec_audio, wav + (long)(r0 + i) * wav_stride, (size_t)Ls[i][0] * sizeof(float),
-                            hipMemcpyHostToDevice, st));
+      H2D(c->ec_audio, wav + (long)(r0 + i) * wav_stride, (size_t)Ls[i][0] * sizeof(float));
       launch_enc_first_conv(c->ec_audio, Ls[i][0], W(c, "encodec.encoder.0.weight"), W(c, "encodec.encoder.0.bias"), c->ec_a, st);
       int C = 32;
       for (int s4 = 0; s4 < 4; ++s4) {
@@ -283,8 +279,8 @@ int vx_encodec_encode(vx_ctx* c, const float* wav, int64_t wav_stride, const int
       launch_rvq_select(c->ec_e0, c->en_scores, c->en_e2 + (size_t)q * 1024, Eq, c->en_codes, q, F, st);
     }
     std::vector<long long> hc((size_t)F * 8);
-    HIPCHK(hipMemcpyAsync(hc.data(), c->en_codes, hc.size() * sizeof(long long), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    D2H(hc.data(), c->en_codes, hc.size() * sizeof(long long));
+    SYNC();
     HIPCHK(hipGetLastError());
     for (int i = 0; i < nb; ++i) {
       out_lens[r0 + i] = seq_len[i];

@@ -37,7 +37,7 @@ int vx_load_tensor(vx_ctx* c, const char* name, const float* data, const int64_t
   void* q = nullptr;
   HIPCHK(hipMalloc(&q, std::max<size_t>(t.n, 1) * sizeof(float)));
   t.d = reinterpret_cast<float*>(q);
-  HIPCHK(hipMemcpy(t.d, data, t.n * sizeof(float), hipMemcpyHostToDevice));
+  H2D(t.d, data, t.n * sizeof(float));
   c->w[name] = t;
   return VX_OK;
 }
@@ -189,7 +189,7 @@ int vx_finalize_weights(vx_ctx* c) {
         pe[(size_t)p * d + 2 * i + 1] = cosf(a);
       }
     if ((e = dev_alloc(c, &c->pe, pe.size(), false))) return e;
-    HIPCHK(hipMemcpy(c->pe, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
+    H2D(c->pe, pe.data(), pe.size() * sizeof(float));
   }
   // a caller-supplied table (built with torch on the host) overrides ours bit for bit
   if (const float* user_pe = W(c, "pe_table")) {
@@ -211,8 +211,8 @@ int vx_finalize_weights(vx_ctx* c) {
         unsigned bits = 0;
         HIPCHK(hipMemsetAsync(d_max, 0, sizeof(unsigned), c->stream));
         launch_absmax(Wt, (long)N * K, d_max, c->stream);
-        HIPCHK(hipMemcpyAsync(&bits, d_max, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        D2H(&bits, d_max, sizeof(unsigned));
+        SYNC();
         float mx;
         memcpy(&mx, &bits, sizeof mx);
         int shift = 24;
@@ -269,7 +269,7 @@ int vx_finalize_weights(vx_ctx* c) {
     for (int j = 0; j < N_Q; ++j) tabs[j] = W(c, "nar_audio_embeddings." + std::to_string(j) + ".word_embeddings.weight");
     float** tmp = nullptr;
     if ((e = dev_alloc(c, &tmp, N_Q, false))) return e;
-    HIPCHK(hipMemcpy((void*)tmp, tabs.data(), N_Q * sizeof(float*), hipMemcpyHostToDevice));
+    H2D((void*)tmp, tabs.data(), N_Q * sizeof(float*));
     c->nar_tabs_dev = const_cast<const float**>(tmp);
   }
 
@@ -302,19 +302,19 @@ int vx_finalize_weights(vx_ctx* c) {
     // embed conv weight (384,128,7) -> [384][tap*128 + c] to match the im2col rows
     {
       std::vector<float> w((size_t)C * 128 * 7), w2((size_t)C * 896);
-      HIPCHK(hipMemcpy(w.data(), W(c, "vocos.backbone.embed.weight"), w.size() * sizeof(float), hipMemcpyDeviceToHost));
+      D2H(w.data(), W(c, "vocos.backbone.embed.weight"), w.size() * sizeof(float)); SYNC();
       for (int o = 0; o < C; ++o)
         for (int ch = 0; ch < 128; ++ch)
           for (int tap = 0; tap < 7; ++tap) w2[(size_t)o * 896 + tap * 128 + ch] = w[((size_t)o * 128 + ch) * 7 + tap];
       if ((e = dev_alloc(c, &c->vc_embed_w, w2.size(), false))) return e;
-      HIPCHK(hipMemcpy(c->vc_embed_w, w2.data(), w2.size() * sizeof(float), hipMemcpyHostToDevice));
+      H2D(c->vc_embed_w, w2.data(), w2.size() * sizeof(float));
     }
     // head weight/bias padded 1282 -> 1408 rows (GEMM N multiple of 128)
     if ((e = dev_alloc(c, &c->vc_head_w, (size_t)NBP * C))) return e;
     if ((e = dev_alloc(c, &c->vc_head_b, NBP))) return e;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(c->vc_head_w, W(c, "vocos.head.out.weight"), (size_t)NB * C * sizeof(float), hipMemcpyDeviceToDevice));
-    HIPCHK(hipMemcpy(c->vc_head_b, W(c, "vocos.head.out.bias"), (size_t)NB * sizeof(float), hipMemcpyDeviceToDevice));
+    SYNC();
+    HIPCHK(hipMemcpyAsync(c->vc_head_w, W(c, "vocos.head.out.weight"), (size_t)NB * C * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->vc_head_b, W(c, "vocos.head.out.bias"), (size_t)NB * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     // inverse real DFT (irfft n=1280, norm="backward") with the hann window folded in, as a [1280][1312] matrix:
     // frame[n] = win[n]/N * ( re0 + (-1)^n re_{N/2} + 2 sum_{k=1}^{N/2-1} re_k cos(2 pi k n/N) - im_k sin(2 pi k n/N) )
     {
@@ -335,8 +335,8 @@ int vx_finalize_weights(vx_ctx* c) {
       }
       if ((e = dev_alloc(c, &c->vc_dft, dft.size(), false))) return e;
       if ((e = dev_alloc(c, &c->vc_win2, win2.size(), false))) return e;
-      HIPCHK(hipMemcpy(c->vc_dft, dft.data(), dft.size() * sizeof(float), hipMemcpyHostToDevice));
-      HIPCHK(hipMemcpy(c->vc_win2, win2.data(), win2.size() * sizeof(float), hipMemcpyHostToDevice));
+      H2D(c->vc_dft, dft.data(), dft.size() * sizeof(float));
+      H2D(c->vc_win2, win2.data(), win2.size() * sizeof(float));
     }
     c->v_rows_cap = std::max<long>((long)c->cfg.max_batch * c->cfg.max_new, 512);   // frames per decode pass (longer inputs: windows)
     const long R = c->v_rows_cap + 128;
@@ -387,20 +387,19 @@ int vx_finalize_weights(vx_ctx* c) {
     auto fetch = [&](const std::string& name, std::vector<float>& host) -> int {
       const Tensor& t = c->w[name];
       host.resize(t.n);
-      HIPCHK(hipMemcpy(host.data(), t.d, t.n * sizeof(float), hipMemcpyDeviceToHost));
+      D2H(host.data(), t.d, t.n * sizeof(float)); SYNC();
       return VX_OK;
     };
     auto upload = [&](const std::vector<float>& host, float** dev) -> int {
       if (int e2 = dev_alloc(c, dev, host.size(), false)) return e2;
-      HIPCHK(hipMemcpy(*dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+      H2D(*dev, host.data(), host.size() * sizeof(float));
       return VX_OK;
     };
     std::vector<float> w, w2, b, b2;
     // RVQ codebooks, concatenated [8*1024][128]
     if ((e = dev_alloc(c, &c->ec_codebook, (size_t)N_Q * 1024 * 128, false))) return e;
     for (int q = 0; q < N_Q; ++q)
-      HIPCHK(hipMemcpy(c->ec_codebook + (size_t)q * 1024 * 128, W(c, "encodec.quantizer." + std::to_string(q) + ".embed"),
-                       (size_t)1024 * 128 * sizeof(float), hipMemcpyDeviceToDevice));
+      HIPCHK(hipMemcpyAsync(c->ec_codebook + (size_t)q * 1024 * 128, W(c, "encodec.quantizer." + std::to_string(q) + ".embed"), (size_t)1024 * 128 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     // first conv (512,128,7) -> [512][tap*128 + c]
     if ((e = fetch("encodec.decoder.0.weight", w))) return e;
     w2.assign((size_t)512 * 896, 0.f);
@@ -566,7 +565,7 @@ int vx_finalize_weights(vx_ctx* c) {
       c->has_encodec_enc = true;
     }
   }
-  HIPCHK(hipStreamSynchronize(c->stream));
+  SYNC();
   HIPCHK(hipGetLastError());
   {
     bool raised = false;          // weights are scaled from their own maximum: only a non-finite weight can raise the flag here
