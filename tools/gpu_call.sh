@@ -17,6 +17,8 @@
 #   lib_ab "base v1 v2" ROUNDS [c_bench args]       the C client on complete library variants (tools/devx_<name>/, _build.py --variant)
 #   gemm_operands                  is gemm_f16x2 power- or schedule-bound: the same launch on random / zero-tail / zero / constant operands
 #   gemm_f32_ab [ROUNDS]           the fp32-MFMA GEMM kernels (register-staged / LDS-DMA 256 x 128 / LDS-DMA 128 x 128) on the four NAR shapes
+#   walk [REPS]                    tile-order sweep of gemm_f16x2_w128 / gemm_f32_dma<256,256> (tools/gemm_walk_sweep.py): us per shape and walk,
+#                                  then FETCH_SIZE per (walk, shape) from one rocprofv3 --pmc pass each -> <tag>_walk_time.txt, <tag>_walk_fetch.csv
 #   power_bench                    board power + sclk from sysfs (tools/power_watch.c) beside two runs of the C client
 #   evidence RND [ARITH]           rocprofv3 --kernel-trace summary + a separate --pmc FETCH_SIZE pass of `bench.py --steps 1 [--arith ARITH]`
 #   mfma RND [ARITH]               three more separate --pmc passes (MFMA / VALU busy, issue stalls) of the same command
@@ -131,6 +133,24 @@ step_gemm_f32_ab() {
       done
     done
   } 2>&1 | tee gpurun_out/${TAG}_gemm_f32_ab.txt
+}
+# tile-order sweep (round 6): time table, then one FETCH_SIZE pass per walk for the two dominant GEMM kernels, split by grid (= shape)
+step_walk() {
+  local reps="${1:-8}"
+  timeout 900 python tools/gemm_walk_sweep.py time "$reps" 2>&1 | tee gpurun_out/${TAG}_walk_time.txt
+  : > gpurun_out/${TAG}_walk_fetch.csv
+  for k in 15 14; do
+    for w in ${WALKS:-default 2 4 8 16 2,c 3,c 4,c}; do
+      ( cd /tmp && export TMPDIR=/tmp
+        rm -rf "$R/gpurun_out/prof_walk"
+        if [ "$w" = default ]; then unset VX_GEMM_WALK; else export VX_GEMM_WALK="$w"; fi
+        timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$R/gpurun_out/prof_walk" -o pmc -- python "$R/tools/gemm_walk_sweep.py" one $k 2 > "$R/gpurun_out/${TAG}_walk_pmc.log" 2>&1
+        DB=$(find "$R/gpurun_out/prof_walk" -name '*.db' | head -1)
+        [ -n "$DB" ] && python "$R/tools/rocpd_pmc_summary.py" "$DB" --by-grid gemm_f16x2_w128 "gemm_f32_dma_kernel<256, 256>" | sed "s/^/$k,\"$w\",/" >> "$R/gpurun_out/${TAG}_walk_fetch.csv"
+        rm -rf "$R/gpurun_out/prof_walk" )
+    done
+  done
+  cat gpurun_out/${TAG}_walk_fetch.csv | cut -c1-200
 }
 step_power_bench() {
   need_cbench || return 1

@@ -132,17 +132,8 @@ __global__ __launch_bounds__(TM * 2, (TM == 256 || NST == 4) ? 1 : 2) void gemm_
   // tiles, in groups of GM row tiles x all column tiles (the A panels of a group stay in that XCD's L2 while W streams)
   constexpr int GM = 8;
   const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + HN - 1) / HN;
-  const int nwg = tiles_m * tiles_n;
-  int wg = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int per_group = GM * tiles_n;
-  const int grp = wg / per_group, in_grp = wg - grp * per_group;
-  const int gm0 = grp * GM;
-  const int gm_rows = (tiles_m - gm0 < GM) ? tiles_m - gm0 : GM;
-  const int tm = gm0 + in_grp % gm_rows, tn = in_grp / gm_rows;
+  int tm, tn;
+  tile_walk(blockIdx.x, tiles_m, tiles_n, GM, g.walk, tm, tn);
   const int m0 = tm * TM, n0 = tn * HN;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -408,17 +399,8 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x2_w128_kernel(GemmX3Args g) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * HSTAGE];
   constexpr int GM = 8;
   const int tiles_m = (g.M + HM - 1) / HM, tiles_n = g.N / TN;
-  const int nwg = tiles_m * tiles_n;
-  int wg = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int per_group = GM * tiles_n;
-  const int grp = wg / per_group, in_grp = wg - grp * per_group;
-  const int gm0 = grp * GM;
-  const int gm_rows = (tiles_m - gm0 < GM) ? tiles_m - gm0 : GM;
-  const int tm = gm0 + in_grp % gm_rows, tn = in_grp / gm_rows;
+  int tm, tn;
+  tile_walk(blockIdx.x, tiles_m, tiles_n, GM, g.walk, tm, tn);
   const int m0 = tm * HM, n0 = tn * TN;
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1, hi = lane >> 5, l31 = lane & 31;
@@ -631,7 +613,9 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x2_w128_kernel(GemmX3Args g) {
 // (fits every measured point within a few percent): a round of 256 x 256 tiles costs 4 u; the 128-row kernel runs two tiles per CU
 // in 2.3 u, a lone one in 1.3 u.  All shapes give bit-identical sums (the per-element accumulation order does not depend on the tile).
 // tn = 128 / 256 / -128: forced (256 x 128 / 256 x 256 on the 8-wave kernel / 128 x 128; benchmarks); 257: 256 x 256 on the 4-wave kernel.
-void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s, int tn) {
+void launch_gemm_f16x2(const GemmX3Args& g_in, hipStream_t s, int tn) {
+  GemmX3Args g = g_in;
+  if (!g.walk) g.walk = gemm_walk_env();
   int tm = HM;
   const int tn_in = tn == 257 ? 0 : tn;          // 257: 256 x 256 tiles forced ON THE FOUR-WAVE KERNEL (benchmarks)
   if (tn == 257) tn = 256;

@@ -16,6 +16,7 @@
 // bijection of the 8 k's onto (step, half) -- the sum is the same set of products (order differs only).
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "vx_common.h"
 
@@ -36,17 +37,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
   // W-panels are shared through L2 instead of 96 A-panels + 1 W-panel (4x fewer L2 fills per K step).
   constexpr int GM = 16;
   const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-  const int nwg = tiles_m * tiles_n;
-  int wg = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int per_group = GM * tiles_n;
-  const int grp = wg / per_group, in_grp = wg - grp * per_group;
-  const int gm0 = grp * GM;
-  const int gm_rows = (tiles_m - gm0 < GM) ? tiles_m - gm0 : GM;   // last group may be short
-  const int tm = gm0 + in_grp % gm_rows, tn = in_grp / gm_rows;
+  int tm, tn;
+  tile_walk(blockIdx.x, tiles_m, tiles_n, GM, g.walk, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -190,17 +182,8 @@ __global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_f32_dma_kernel
 
   constexpr int GM = TM == 256 ? 8 : 16;
   const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
-  const int nwg = tiles_m * tiles_n;
-  int wg = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int per_group = GM * tiles_n;
-  const int grp = wg / per_group, in_grp = wg - grp * per_group;
-  const int gm0 = grp * GM;
-  const int gm_rows = (tiles_m - gm0 < GM) ? tiles_m - gm0 : GM;
-  const int tm = gm0 + in_grp % gm_rows, tn = in_grp / gm_rows;
+  int tm, tn;
+  tile_walk(blockIdx.x, tiles_m, tiles_n, GM, g.walk, tm, tn);
   const int m0 = tm * TM, n0 = tn * TN;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -377,7 +360,21 @@ __global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_f32_dma_kernel
 // variant 0: the product's choice -- the LDS-DMA kernel for long row sets whose operands it can address (16-B aligned rows), the
 // register-staged kernel otherwise (Vocos / EnCodec: short row sets, N = 1282 / 1025 ...);  1 / 2 / 3 / 4: register-staged / DMA 256 x 128 /
 // DMA 128 x 128 / DMA 256 x 256 forced (A/B; VX_GEMM_F32_VARIANT in the environment forces one for a whole process)
-void launch_gemm_f32(const GemmArgs& g, hipStream_t s, int variant) {
+int gemm_walk_env() {
+  static const int walk = [] {
+    const char* e = getenv("VX_GEMM_WALK");
+    if (!e || !*e) return 0;
+    const int gm = atoi(e);
+    if (gm < 1 || gm > 255) return 0;
+    const char* comma = strchr(e, ',');
+    return gm | ((comma && comma[1] == 'c') ? 256 : 0);
+  }();
+  return walk;
+}
+
+void launch_gemm_f32(const GemmArgs& g_in, hipStream_t s, int variant) {
+  GemmArgs g = g_in;
+  if (!g.walk) g.walk = gemm_walk_env();
   if (g.M <= 0 || g.N <= 0) return;
   if (variant == 0) {
     static const int env = [] { const char* e = getenv("VX_GEMM_F32_VARIANT"); return e ? atoi(e) : 0; }();

@@ -35,6 +35,7 @@ struct GemmArgs {
   int M, N, K;
   int act;
   const int* row_gather;    // optional: A row index per output row (null = identity)
+  int walk;                 // tile order override (tile_walk below): 0 = the kernel's own; else group depth | column-fastest << 8
 };
 void launch_gemm_f32(const GemmArgs& g, hipStream_t s, int variant = 0);   // variant: gemm_f32.hip (0 = product choice)
 
@@ -56,6 +57,7 @@ struct GemmX3Args {
   float descale;                                // f16x2: 2^-(shift of A + shift of W), applied to the accumulator (exact)
   const int* resid_rows;                        // f16x2 only, optional: row of `resid` for output row m (null = m): compacted row sets
   int dev_variant;                              // tools builds only (-DVX_DEV_PROBES): > 0 selects a wave-priority variant of the 256 x 256 kernel
+  int walk;                                     // tile order override (tile_walk below): 0 = the kernel's own; else group depth | column-fastest << 8
 };
 void launch_gemm_f16x2(const GemmX3Args& g, hipStream_t s, int tn = 0);     // 256 x (256 | 128) x 32 tiles, async LDS fill, any M
 // f16x2 planes are TILE-major: [rows / tile_rows][K/32][tile_rows][32], tile_rows = 256 (both operands);
@@ -67,7 +69,28 @@ constexpr int H2_TILE_A = 256, H2_TILE_W = 256;
 // fp16 subnormal (v_mfma honours them): absolute error <= 2^-25 * 2^-shift, far below fp32 resolution of the sums.
 constexpr int H2_ACT_SHIFT = 5;
 constexpr float H2_ACT_SCALE = 32.0f;
+// VX_GEMM_WALK="<group depth>[,c]" (read once per process by the GEMM launchers; kernel development: tools/gemm_walk_sweep.py)
+int gemm_walk_env();
 #if defined(__HIPCC__)
+// Tile order of the dense GEMM kernels.  (1) XCD-aware: consecutive workgroup ids land on different XCDs (id % 8), each with a
+// private 4 MiB L2, so ids are remapped to give every XCD one contiguous run of the order.  (2) Inside that order tiles come in
+// groups of `gm` row tiles x all column tiles; inside a group the row tile runs fastest (walk >> 8 == 0: the ~32 workgroups an XCD
+// keeps resident cover gm row tiles x 32 / gm column tiles) or the column tile does (walk >> 8 == 1: 32 / tiles_n row tiles x all
+// column tiles).  walk == 0 keeps the kernel's measured default (row-fastest, gm_default).
+__device__ __forceinline__ void tile_walk(int wg, int tiles_m, int tiles_n, int gm_default, int walk, int& tm, int& tn) {
+  const int nwg = tiles_m * tiles_n;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int GM = walk ? (walk & 255) : gm_default;
+  const int per_group = GM * tiles_n;
+  const int grp = wg / per_group, in_grp = wg - grp * per_group;
+  const int gm0 = grp * GM;
+  const int gm_rows = (tiles_m - gm0 < GM) ? tiles_m - gm0 : GM;   // last group may be short
+  if (walk >> 8) { tm = gm0 + in_grp / tiles_n; tn = in_grp - (in_grp / tiles_n) * tiles_n; }
+  else { tm = gm0 + in_grp % gm_rows; tn = in_grp / gm_rows; }
+}
 __device__ __forceinline__ void h2_split(float x, float scale, _Float16& h, _Float16& t, bool& bad) {
   const float X = x * scale;                    // power of two: exact
   bad |= !(fabsf(X) < 65504.0f);
