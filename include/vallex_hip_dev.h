@@ -41,6 +41,11 @@ int vx_bench_attn(vx_ctx* ctx, int32_t batch, int32_t len, int32_t causal, int32
 int vx_bench_gemm_clock(vx_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t kernel, int32_t reps, double* avg_us,
                         double* max_abs_diff, double* clock_mhz);
 
+/* Epilogue cross-check of the two f16x2 GEMM kernels on the same operand planes (four waves of 128 x 128 against eight waves of
+ * 64 x 128; bit-identical by construction): mode 0 = bias + ReLU + out_planes, 1 = bias + residual through resid_rows (ragged M),
+ * 2 = bias + residual in place.  differing / compared = 32-bit words of C (16-bit words of the planes in mode 0).  N % 256 == 0. */
+int vx_bench_gemm_epilogue(vx_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t mode, int64_t* differing, int64_t* compared);
+
 #ifdef __cplusplus
 }
 #endif

@@ -135,3 +135,20 @@ def test_full_length_nar_logits_batched_dma_gemm():
         np.testing.assert_allclose(lg[T[0]:T[0] + 16], gs[1]["nar_logits"][st], atol=NAR_TOL, rtol=0, err_msg=f"stage {st} row 1")
     for cd, g in zip(codes, gs):
         np.testing.assert_array_equal(cd, g["codes"][0])
+
+
+def test_bench_row0_matches_live_reference_golden():
+    """round 6: row 0 of bench.py's workload (synthetic prompt, Tp = 221, S = 167, top-k 10 with the uniforms bench.py injects,
+    600 frames) against the ids the LIVE reference's own VALLE.inference produced for it (tests/golden/bench_row0.npz, written by
+    tools/cpu_reference.py) -- the fixture behind `parity.*.ids_equal_reference_golden` of the bench line"""
+    import os
+    import bench
+    from oracle.make_golden import GOLD
+    g = np.load(os.path.join(GOLD, "bench_row0.npz"))
+    frames = int(g["frames"])
+    r = bench.make_rows(0, 1)[0]
+    us = np.random.default_rng(1234).random(frames + 1).astype(np.float32)
+    m = _model()
+    out = m.inference_batch([r], top_k=10, uniforms=us[:, None], force_eos_at=frames)[0]
+    gold = g["codes"].astype(np.int64)
+    assert out.shape == gold.shape and _first_diff(out, gold) is None, (out.shape, _first_diff(out, gold), float(g["ar_margin"].min()))

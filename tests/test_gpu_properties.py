@@ -203,3 +203,18 @@ def test_f16x2_four_wave_gemm_equals_the_eight_wave_kernel():
     for (M, N, K) in ((31616, 3072, 1024), (31616, 1024, 4096), (2049, 1024, 1024), (300, 256, 64)):
         d4, d8 = eng.bench_gemm(M, N, K, 15, 1)[1], eng.bench_gemm(M, N, K, 8, 1)[1]
         assert d4 == d8 and d4 < 2e-3, (M, N, K, d4, d8)
+
+
+@pytest.mark.gpu
+def test_f16x2_four_wave_gemm_epilogue_branches_equal_the_eight_wave_kernel_word_for_word():
+    """round 6 (ADVICE): the four-wave kernel's rewritten epilogue -- bias staged through LDS, residual vectors prefetched one block
+    ahead, resid_rows clamping, the out_planes split with its lane exchange -- against the eight-wave kernel on the same operand planes,
+    reached DIRECTLY (vx_bench_gemm_epilogue), not through whatever tile the cost model picks at a model test's row count:
+    mode 0 bias + ReLU + out_planes (linear1), 1 bias + residual through a scattered resid_rows map (trimmed out_proj), 2 bias + residual
+    in place (out_proj / linear2); full and ragged row counts, K of two tiles and of 128 tiles.  Every word must be identical."""
+    import vallex_amd
+    eng = vallex_amd.Engine(num_layers=1, max_batch=1, max_text=8, max_prompt=8, max_new=8, with_vocos=False)
+    for (M, N, K) in ((4096, 1024, 1024), (2049, 1024, 4096), (983, 4096, 1024), (257, 256, 64), (19200, 1024, 1024)):
+        for mode in (0, 1, 2):
+            bad, tot = eng.bench_gemm_epilogue(M, N, K, mode)
+            assert bad == 0 and tot >= M * N, (M, N, K, mode, bad, tot)

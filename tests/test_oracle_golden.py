@@ -301,3 +301,23 @@ def test_round3_fixture_shapes():
     # the UI call: the best beam ended by itself, the worst ran to the forced end; same weights, same draws
     best, worst = (np.load(os.path.join(GOLD, n + ".npz"))["codes"] for n in ("nl12_ui_bestof5_ja", "nl12_ui_bestof5_ja_worst"))
     assert best.shape == (1, 9, 8) and worst.shape == (1, 120, 8) and int(max(best.max(), worst.max())) < 1024
+
+
+def test_oracle_matches_reference_on_bench_row0():
+    """the utterance bench.py's cpu_baseline leg computes on the oracle (and its parity block compares the engine against): row 0 of
+    the bench workload, 12 layers, 600 frames, top-k 10 with the injected uniforms -- the oracle's ids against the ids of the LIVE
+    reference for the same utterance (tests/golden/bench_row0.npz, tools/cpu_reference.py).  AR only past the first 64 frames would
+    not be cheaper: the NAR stages need all 600."""
+    import torch
+    import bench
+    g = np.load(os.path.join(GOLD, "bench_row0.npz"))
+    frames = int(g["frames"])
+    r = bench.make_rows(0, 1)[0]
+    us = np.random.default_rng(1234).random(frames + 1).astype(np.float32)
+    orc = VallexOracle(synth.vallex_state_dict(bench.NUM_LAYERS, 0, eos_gain=0.0), bench.NUM_LAYERS)
+    text = torch.from_numpy(r["text"].astype(np.int64))
+    prompts = torch.from_numpy(r["prompt"].astype(np.int64))
+    with torch.no_grad():
+        gen = orc.ar_generate(text, prompts[:, 0], r["enroll"], r["prompt_language"], r["text_language"], 10, 1.0, us, frames, None)
+        codes = orc.nar_generate(text, prompts, gen, r["enroll"], r["prompt_language"], r["text_language"], None)
+    np.testing.assert_array_equal(np.asarray(codes), g["codes"].astype(np.int64))

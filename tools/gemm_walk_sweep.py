@@ -26,8 +26,33 @@ def one(kernel: int, reps: int):
         print(f"RESULT {kernel} {N} {K} {us:.2f} {md:.3e}", flush=True)
 
 
+def ab(rounds: int, reps: int):
+    """candidates against the pre-round-6 order (-1 = 8 deep, row-fastest), interleaved in ONE process: per shape, `rounds` rounds of
+    [old, cand1, cand2, ...]; prints every round and the per-candidate median ratio to `old` of the same round"""
+    import statistics
+    import vallex_amd
+    eng = vallex_amd.Engine(num_layers=1, max_batch=1, max_text=8, max_prompt=8, max_new=8, with_vocos=False)
+    cands = os.environ.get("WALK_CANDS", "-1 0 8,c 4,c 2,c").split()
+    for kernel, name in ((15, "gemm_f16x2_w128"), (14, "gemm_f32_dma<256,256>")):
+        for (N, K) in SHAPES:
+            ratios = {w: [] for w in cands}
+            for r in range(rounds):
+                row = {}
+                for w in cands:
+                    os.environ["VX_BENCH_GEMM_WALK"] = w
+                    row[w] = eng.bench_gemm(M, N, K, kernel, reps)[0]
+                for w in cands:
+                    ratios[w].append(row[w] / row[cands[0]])
+                print(f"{name} N={N} K={K} round {r}: " + "  ".join(f"{w}: {row[w]:7.1f}" for w in cands), flush=True)
+            print(f"{name} N={N} K={K} MEDIAN ratio to '{cands[0]}': " + "  ".join(f"{w}: {statistics.median(ratios[w]):.4f}" for w in cands), flush=True)
+    os.environ.pop("VX_BENCH_GEMM_WALK", None)
+
+
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "time"
+    if mode == "ab":
+        ab(int(sys.argv[2]) if len(sys.argv) > 2 else 5, int(sys.argv[3]) if len(sys.argv) > 3 else 6)
+        return
     if mode == "one":
         one(int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 3)
         return

@@ -19,6 +19,8 @@
 #   gemm_f32_ab [ROUNDS]           the fp32-MFMA GEMM kernels (register-staged / LDS-DMA 256 x 128 / LDS-DMA 128 x 128) on the four NAR shapes
 #   walk [REPS]                    tile-order sweep of gemm_f16x2_w128 / gemm_f32_dma<256,256> (tools/gemm_walk_sweep.py): us per shape and walk,
 #                                  then FETCH_SIZE per (walk, shape) from one rocprofv3 --pmc pass each -> <tag>_walk_time.txt, <tag>_walk_fetch.csv
+#   sb_sweep                       small-batch split counts against the context length (1 row: VX_SB_QKV_NSPLIT x prompt length; 8 rows:
+#                                  VX_ATT_NSPLIT, VX_QKV_BALANCED at context ~1300) with the C client -> <tag>_cbench.txt
 #   power_bench                    board power + sclk from sysfs (tools/power_watch.c) beside two runs of the C client
 #   evidence RND [ARITH]           rocprofv3 --kernel-trace summary + a separate --pmc FETCH_SIZE pass of `bench.py --steps 1 [--arith ARITH]`
 #   mfma RND [ARITH]               three more separate --pmc passes (MFMA / VALU busy, issue stalls) of the same command
@@ -151,6 +153,37 @@ step_walk() {
     done
   done
   cat gpurun_out/${TAG}_walk_fetch.csv | cut -c1-200
+}
+# small batches (round 6): the split counts that are constants today, swept against the context length with the C client
+#   1 row:  VX_SB_QKV_NSPLIT 4 / 8 / 16 (fused norm1 + QKV + attention launch) x prompt 100 / 500 / 1000 frames (mean context ~400 / 800 / 1300)
+#   8 rows: VX_ATT_NSPLIT 1 / 2 / 4 / 8 (context splits of dec_attn on the general chain) and VX_QKV_BALANCED 0 / 1, prompt 1000 frames
+step_sb_sweep() {
+  need_cbench || return 1
+  printf "%-34s %8s %8s %8s %8s  %s\n" point ms_step ar_ms nar_ms audio_s digest | tee -a gpurun_out/${TAG}_cbench.txt
+  for tp in 100 500 1000; do
+    for ns in 4 8 16; do
+      for r in 1 2; do step_cbench "rows1 tp$tp SB_QKV_NSPLIT=$ns" VX_SB_QKV_NSPLIT=$ns -- --rows 1 --tp $tp --frames 300 --steps 3 --warmup 1 --no-vocos; done
+    done
+    step_cbench "rows1 tp$tp SB_QKV=0 (5 launches)" VX_SB_QKV=0 -- --rows 1 --tp $tp --frames 300 --steps 3 --warmup 1 --no-vocos
+  done
+  for ns in 1 2 4 8; do
+    for r in 1 2; do step_cbench "rows8 tp1000 ATT_NSPLIT=$ns" VX_ATT_NSPLIT=$ns -- --rows 8 --tp 1000 --frames 300 --steps 3 --warmup 1 --no-vocos; done
+  done
+  for v in 0 1; do
+    for r in 1 2; do step_cbench "rows8 tp1000 QKV_BALANCED=$v" VX_QKV_BALANCED=$v -- --rows 8 --tp 1000 --frames 300 --steps 3 --warmup 1 --no-vocos; done
+  done
+}
+# mid-size batches: context splits of dec_attn (VX_ATT_NSPLIT; 0 = the engine's rule) for 5 / 8 / 12 / 16 rows at short and long contexts
+step_sb_sweep2() {
+  need_cbench || return 1
+  printf "%-34s %8s %8s %8s %8s  %s\n" point ms_step ar_ms nar_ms audio_s digest | tee -a gpurun_out/${TAG}_cbench.txt
+  for rows in ${SB2_ROWS:-5 8 12 16}; do
+    for tp in 200 1000; do
+      for ns in 0 1 2 3 4 6; do
+        step_cbench "rows$rows tp$tp ATT_NSPLIT=$ns" VX_ATT_NSPLIT=$ns -- --rows $rows --tp $tp --frames 300 --steps 3 --warmup 1 --no-vocos
+      done
+    done
+  done
 }
 step_power_bench() {
   need_cbench || return 1

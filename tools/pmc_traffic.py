@@ -60,13 +60,17 @@ def main(csv_path, rnd, arith=""):
             continue
         n = sum(int(r["dispatches"]) for r in sel)
         avg_kb = sum(float(r["avg"]) * int(r["dispatches"]) for r in sel) / n
+        # one entry per kernel SYMBOL of the class (round 5 quoted the 8-wave kernel's figure for the 4-wave kernel: the class average
+        # and the prose were read off different rows of the same CSV -- the rows are now part of the file the prose is generated from)
+        by_symbol = [{"kernel": r["kernel"], "launches": int(r["dispatches"]), "traffic_bytes_per_launch": int(float(r["avg"]) * 1024 * 2),
+                      "avg_dispatch_us": float(r["avg_dispatch_us"])} for r in sel]
         out = {"kernel": sub, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python bench.py --steps 1 --warmup 0 "
                                         "--no-cpu-baseline --no-profile --no-ref-arith" + (f" --arith {arith}" if arith else "")
                                         + " (tools/pmc_traffic.py)",
                "launches": n, "avg_FETCH_SIZE_KB": round(avg_kb, 1),
                "correction": "x2: gfx950 FETCH_SIZE tallies the 128-B requests of wide (16 B/lane) streaming reads at 64 B "
                              "(MI355X_MICROARCH.md, HBM)",
-               "traffic_bytes_per_launch": int(avg_kb * 1024 * 2),
+               "traffic_bytes_per_launch": int(avg_kb * 1024 * 2), "by_symbol": by_symbol,
                # bench.py refuses the file once the kernel's translation unit (or vx_common.h) has changed
                "source_sha256": bench.kernel_source_digest(key)}
         if key == "dec_attn":
@@ -77,5 +81,19 @@ def main(csv_path, rnd, arith=""):
         print(p, out["traffic_bytes_per_launch"])
 
 
+def table(csv_path):
+    """markdown table, one row per kernel symbol: launches, FETCH_SIZE per launch (x2 corrected), launch time under the counter pass"""
+    rows = [r for r in csv.DictReader(open(csv_path)) if r["counter"] == "FETCH_SIZE"]
+    rows.sort(key=lambda r: -float(r["avg"]) * int(r["dispatches"]))
+    out = ["| kernel symbol | launches | FETCH per launch (MB, x2 corrected) | total (GB) | avg launch under the counter pass (us) |", "|---|---|---|---|---|"]
+    for r in rows:
+        mb = float(r["avg"]) * 1024 * 2 / 1e6
+        out.append(f"| `{r['kernel']}` | {r['dispatches']} | {mb:.1f} | {mb * int(r['dispatches']) / 1e3:.2f} | {r['avg_dispatch_us']} |")
+    return "\n".join(out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--table":
+        print(table(sys.argv[2]))
+        sys.exit(0)
     main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "02", sys.argv[3] if len(sys.argv) > 3 else "")

@@ -65,7 +65,7 @@ SYMBOLS = ["vx_abi_version", "vx_create", "vx_destroy", "vx_last_error", "vx_syn
            "vx_fallback_reset", "vx_arith_mode"]
 # ... and include/vallex_hip_dev.h: measurement / kernel development, never called by the mirrors of the reference API
 DEV_SYMBOLS = ["vx_prof_enable", "vx_prof_get", "vx_prof_reset", "vx_bench_kernel", "vx_bench_gemm", "vx_bench_attn",
-               "vx_bench_gemm_clock"]
+               "vx_bench_gemm_clock", "vx_bench_gemm_epilogue"]
 
 _lib = None
 
@@ -120,6 +120,7 @@ def load_library() -> C.CDLL:
     lib.vx_bench_kernel.argtypes = [ctx, C.c_int32, C.c_int32, C.c_int32, P(C.c_double), P(C.c_double)]
     lib.vx_bench_gemm.argtypes = [ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P(C.c_double), P(C.c_double)]
     lib.vx_bench_attn.argtypes = [ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P(C.c_double), P(C.c_double)]
+    lib.vx_bench_gemm_epilogue.argtypes = [ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P(C.c_int64), P(C.c_int64)]
     lib.vx_bench_gemm_clock.argtypes = [ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P(C.c_double), P(C.c_double),
                                         P(C.c_double)]
     lib.vx_last_stats.argtypes = [ctx, P(C.c_int64), P(C.c_int64), P(C.c_double), P(C.c_double)]
@@ -372,6 +373,13 @@ class Engine:
         us, md = C.c_double(), C.c_double()
         self._chk(self.lib.vx_bench_gemm(self.ctx, M, N, K, kernel, reps, C.byref(us), C.byref(md)))
         return us.value, md.value
+
+    def bench_gemm_epilogue(self, M: int, N: int, K: int, mode: int):
+        """(differing words, compared words) of the four-wave f16x2 kernel against the eight-wave one under epilogue `mode`
+        (0 bias + ReLU + out_planes, 1 bias + residual through resid_rows, 2 bias + residual) -- include/vallex_hip_dev.h"""
+        bad, tot = C.c_int64(), C.c_int64()
+        self._chk(self.lib.vx_bench_gemm_epilogue(self.ctx, M, N, K, mode, C.byref(bad), C.byref(tot)))
+        return bad.value, tot.value
 
     def bench_gemm_clock(self, M: int, N: int, K: int, kernel: int = 6, reps: int = 8):
         """(avg_us, max |diff| to the fp32 kernel, shader clock in MHz held WHILE the kernel runs) -- include/vallex_hip_dev.h"""

@@ -238,6 +238,15 @@ static int bench_gemm_impl(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t k
   gx.descale = ldexpf(1.0f, -(H2_ACT_SHIFT + 14));
   GemmArgs g1 = g0;
   g1.C = C1;
+  // VX_BENCH_GEMM_WALK="<gm>[,c]" (read at EVERY call of the harness, unlike the launchers' VX_GEMM_WALK): tile-order A/B inside one
+  // process, interleaved (tools/gemm_walk_sweep.py ab); -1 = the order the kernels had before round 6 (8 row tiles deep, row-fastest)
+  if (const char* we = getenv("VX_BENCH_GEMM_WALK")) {
+    const int gm = atoi(we);
+    const char* comma = strchr(we, ',');
+    const int wk = gm == -1 ? 8 : ((gm >= 1 && gm <= 255) ? (gm | ((comma && comma[1] == 'c') ? 256 : 0)) : 0);
+    gx.walk = wk;
+    g1.walk = wk;
+  }
   auto run = [&]() {
     if (kernel == 0) launch_gemm_f32(g1, c->stream);                       // fp32 MFMA, the product's choice of kernel
     else if (kernel >= 3 && kernel <= 5) launch_gemm_f32(g1, c->stream, kernel - 2);   // 3 register-staged / 4 LDS-DMA 256 x 128 / 5 LDS-DMA 128 x 128
@@ -298,16 +307,23 @@ static int bench_gemm_impl(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t k
     (void)hipFree(d_clk);
     (void)hipStreamDestroy(s2);
   }
-  const int rows = std::min(M, 256);
-  std::vector<float> h0((size_t)rows * N), h1((size_t)rows * N);
-  D2H(h0.data(), C0, h0.size() * 4); SYNC();
-  D2H(h1.data(), C1, h1.size() * 4); SYNC();
-  // also the LAST rows (tile tails)
+  // every output row against the register-staged fp32 kernel (round 6: interior tiles, the XCD remap and the tile-walk grouping are
+  // compared too, not only the first and the last 256 rows), in chunks through the pinned ring
   double md = 0;
-  for (size_t i = 0; i < h0.size(); ++i) md = std::max(md, (double)fabsf(h0[i] - h1[i]));
-  D2H(h0.data(), C0 + (size_t)(M - rows) * N, h0.size() * 4); SYNC();
-  D2H(h1.data(), C1 + (size_t)(M - rows) * N, h1.size() * 4); SYNC();
-  for (size_t i = 0; i < h0.size(); ++i) md = std::max(md, (double)fabsf(h0[i] - h1[i]));
+  {
+    const int chunk = std::max(1, std::min(M, (int)((16u << 20) / ((size_t)N * 4))));
+    std::vector<float> h0((size_t)chunk * N), h1((size_t)chunk * N);
+    for (int r0 = 0; r0 < M; r0 += chunk) {
+      const size_t n = (size_t)std::min(chunk, M - r0) * N;
+      D2H(h0.data(), C0 + (size_t)r0 * N, n * 4);
+      D2H(h1.data(), C1 + (size_t)r0 * N, n * 4);
+      SYNC();
+      for (size_t i = 0; i < n; ++i) {
+        const double d = (double)fabsf(h0[i] - h1[i]);
+        md = d > md || d != d ? (d != d ? 1e30 : d) : md;        // a NaN on either side is a mismatch, not a silent pass
+      }
+    }
+  }
   *max_abs_diff = md;
 #undef TRY
   cleanup();
@@ -399,6 +415,109 @@ int vx_bench_attn(vx_ctx* c, int32_t batch, int32_t len, int32_t causal, int32_t
 #undef TRY
   cleanup();
   HIPCHK(hipGetLastError());
+  return VX_OK;
+}
+
+
+// Epilogue cross-check of the two f16x2 GEMM kernels (round 6, ADVICE): the four-wave 128 x 128 kernel (gemm_f16x2_w128_kernel, every
+// 256 x 256 tile of the product) against the eight-wave kernel on the SAME operand planes, with the epilogue branches the plain
+// micro-benchmark never reaches:  mode 0 = bias + ReLU + out_planes (linear1: the result leaves as the next GEMM's A planes);
+// mode 1 = bias + residual read through resid_rows (the trimmed out_proj of the last NAR layer) on whatever ragged M was asked for;
+// mode 2 = bias + residual, rows in place (out_proj / linear2).  Both kernels accumulate an output element in the same order, so
+// every fp32 result and every plane half-word must be IDENTICAL: returns the number of differing 32-bit words of C (modes 1, 2) or
+// 16-bit words of the planes (mode 0), and how many words were compared.
+int vx_bench_gemm_epilogue(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t mode, int64_t* differing, int64_t* compared) {
+  if (!c || M <= 0 || N <= 0 || K < 64 || K % 32 || N % 256 || mode < 0 || mode > 2 || !differing || !compared) return VX_EINVAL;
+  HIPCHK(hipSetDevice(c->dev));
+  const long a_pl = h2_plane(M, K, H2_TILE_A), w_pl = h2_plane(N, K, H2_TILE_W), o_pl = h2_plane(M, N, H2_TILE_A);
+  float *A = nullptr, *Wt = nullptr, *bias = nullptr, *resid = nullptr, *C0 = nullptr, *C1 = nullptr;
+  unsigned short *A3 = nullptr, *W3 = nullptr, *P0 = nullptr, *P1 = nullptr;
+  int *rows = nullptr, *flag = nullptr;
+  const int RR = M + 77;                                    // rows of the residual source (mode 1 reads it through a row map)
+  auto cleanup = [&]() {
+    for (void* p : {(void*)A, (void*)Wt, (void*)bias, (void*)resid, (void*)C0, (void*)C1, (void*)A3, (void*)W3, (void*)P0, (void*)P1, (void*)rows,
+                    (void*)flag})
+      if (p) (void)hipFree(p);
+  };
+  hipError_t he;
+#define TRY(x) if ((he = (x)) != hipSuccess) { cleanup(); c->err = std::string(#x) + ": " + hipGetErrorString(he); return VX_EHIP; }
+  TRY(hipMalloc((void**)&A, (size_t)M * K * 4));
+  TRY(hipMalloc((void**)&Wt, (size_t)N * K * 4));
+  TRY(hipMalloc((void**)&bias, (size_t)N * 4));
+  TRY(hipMalloc((void**)&resid, (size_t)RR * N * 4));
+  TRY(hipMalloc((void**)&C0, (size_t)M * N * 4));
+  TRY(hipMalloc((void**)&C1, (size_t)M * N * 4));
+  TRY(hipMalloc((void**)&A3, (size_t)2 * a_pl * 2));
+  TRY(hipMalloc((void**)&W3, (size_t)2 * w_pl * 2));
+  TRY(hipMalloc((void**)&P0, (size_t)2 * o_pl * 2));
+  TRY(hipMalloc((void**)&P1, (size_t)2 * o_pl * 2));
+  TRY(hipMalloc((void**)&rows, (size_t)M * 4));
+  TRY(hipMalloc((void**)&flag, 4));
+  TRY(hipMemsetAsync(A3, 0, (size_t)2 * a_pl * 2, c->stream));
+  TRY(hipMemsetAsync(W3, 0, (size_t)2 * w_pl * 2, c->stream));
+  TRY(hipMemsetAsync(P0, 0, (size_t)2 * o_pl * 2, c->stream));
+  TRY(hipMemsetAsync(P1, 0, (size_t)2 * o_pl * 2, c->stream));
+  TRY(hipMemsetAsync(C0, 0, (size_t)M * N * 4, c->stream));
+  TRY(hipMemsetAsync(C1, 0, (size_t)M * N * 4, c->stream));
+  TRY(hipMemsetAsync(flag, 0, 4, c->stream));
+  {
+    unsigned long long st = 0x2545F4914F6CDD1Dull;
+    auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (float)((st >> 40) & 0xFFFFFF) / 8388608.0f - 1.0f; };
+    std::vector<float> h((size_t)std::max<long>((long)std::max(M, N) * K, (long)RR * N));
+    for (size_t i = 0; i < (size_t)M * K; ++i) h[i] = rnd();
+    H2D(A, h.data(), (size_t)M * K * 4);
+    for (size_t i = 0; i < (size_t)N * K; ++i) h[i] = rnd();
+    H2D(Wt, h.data(), (size_t)N * K * 4);
+    for (size_t i = 0; i < (size_t)N; ++i) h[i] = rnd();
+    H2D(bias, h.data(), (size_t)N * 4);
+    for (size_t i = 0; i < (size_t)RR * N; ++i) h[i] = 3.0f * rnd();
+    H2D(resid, h.data(), (size_t)RR * N * 4);
+    std::vector<int> rm(M);
+    for (int i = 0; i < M; ++i) rm[i] = (int)(((long)i * 7919 + 13) % RR);       // a scattered, non-monotonic row map
+    H2D(rows, rm.data(), (size_t)M * 4);
+  }
+  launch_split2h(A, K, M, K, nullptr, A3, a_pl, H2_TILE_A, nullptr, H2_ACT_SCALE, c->stream);
+  launch_split2h(Wt, K, N, K, nullptr, W3, w_pl, H2_TILE_W, nullptr, 16384.0f, c->stream);
+  GemmX3Args g{};
+  g.A = A3; g.a_plane = a_pl; g.W = W3; g.w_plane = w_pl; g.bias = bias; g.M = M; g.N = N; g.K = K; g.ldc = N;
+  g.descale = ldexpf(1.0f, -(H2_ACT_SHIFT + 14)); g.range_flag = flag;
+  if (mode == 0) { g.act = ACT_RELU; g.out_plane = o_pl; }
+  else { g.act = ACT_NONE; g.resid = resid; g.ldr = N; if (mode == 1) g.resid_rows = rows; }
+  GemmX3Args g0 = g, g1 = g;
+  if (mode == 0) { g0.out_planes = P0; g1.out_planes = P1; } else { g0.C = C0; g1.C = C1; }
+  launch_gemm_f16x2(g0, c->stream, 256);        // eight waves of 64 x 128
+  launch_gemm_f16x2(g1, c->stream, 257);        // four waves of 128 x 128
+  SYNC();
+  TRY(hipGetLastError());
+  int64_t bad = 0, total = 0;
+  if (mode == 0) {
+    // the planes are tile-major with pad rows inside the last row tile: compare the whole allocation (pads were zeroed on both sides)
+    const size_t words = (size_t)2 * o_pl, chunk = (size_t)8 << 20;
+    std::vector<unsigned short> h0(chunk), h1(chunk);
+    for (size_t o = 0; o < words; o += chunk) {
+      const size_t n = std::min(chunk, words - o);
+      D2H(h0.data(), P0 + o, n * 2);
+      D2H(h1.data(), P1 + o, n * 2);
+      SYNC();
+      for (size_t i = 0; i < n; ++i) bad += h0[i] != h1[i];
+      total += (int64_t)n;
+    }
+  } else {
+    const size_t words = (size_t)M * N, chunk = (size_t)4 << 20;
+    std::vector<unsigned> h0(chunk), h1(chunk);
+    for (size_t o = 0; o < words; o += chunk) {
+      const size_t n = std::min(chunk, words - o);
+      D2H(h0.data(), C0 + o, n * 4);
+      D2H(h1.data(), C1 + o, n * 4);
+      SYNC();
+      for (size_t i = 0; i < n; ++i) bad += h0[i] != h1[i];
+      total += (int64_t)n;
+    }
+  }
+#undef TRY
+  cleanup();
+  *differing = bad;
+  *compared = total;
   return VX_OK;
 }
 

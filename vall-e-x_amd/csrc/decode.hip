@@ -145,13 +145,15 @@ void launch_skinny_gemm(const float* Wp, const float* xp, float* partial, int Np
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// EXPERIMENT (VX_QKV_BALANCED=1): the in_proj GEMM of the decode step on a grid that divides the chip.  skinny_gemm_kernel runs it as
+// DEFAULT in_proj of the 32-row decode chain since round 5 (VX_QKV_BALANCED=0 reverts to skinny_gemm_kernel with 4 K slices; the two
+// sum q in a different order, so their logits are not bit-identical to each other -- every golden is bit-exact under both, tools/
+// gpu_call.sh `switches`): the in_proj GEMM of the decode step on a grid that divides the chip.  skinny_gemm_kernel runs it as
 // 96 column tiles x 4 K slices = 384 workgroups on 256 CUs: half the CUs stream two 32 KB tiles, the other half one, and the launch
 // ends with the loaded half (profiles/r02_step_timeline.log: average workgroup done at 3.7 us, last at 5.3 us; linear2 with its 256
 // workgroups 4.8 / 5.6).  Here the 32 column tiles of q are cut into EIGHT K slices (256 workgroups x 16 KB) and the 64 tiles of k, v
 // stay at four (256 workgroups x 32 KB): 512 workgroups, dispatched in block-id order two per CU, one of each kind = 48 KB on every CU.
 // k and v: the arithmetic of skinny_gemm_kernel with splitk = 4, operation for operation (same slabs).  q: eight slabs instead of four
-// (a different summation order: dec_attn_kernel<*, 84> sums them, and the goldens decide).  Slab layout unchanged,
+// (a different summation order: dec_attn_kernel<*, SK_QKV_BALANCED> sums them, and the goldens decide).  Slab layout unchanged,
 // out[(ks * MB + b) * 3072 + n]; the k / v columns of slabs 4..7 are never written or read.
 __global__ __launch_bounds__(256, 2) void skinny_qkv_bal_kernel(const float* __restrict__ Wp, const float* __restrict__ xp,
                                                              float* __restrict__ out) {
@@ -1330,12 +1332,12 @@ bool launch_dec_attn_qkv(const float* in_w, const float* in_b, float* kc, float*
 bool launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias, float* kc, float* vc, int Tmax,
                      const int* slot_meta, float* xp_out, float* part_o, float* part_ml, int nsplit, int batch,
                      const float* wo_heads, float* out_heads, hipStream_t s) {
-  if (splitk == 84) {                      // 8 slabs of q, 4 of k / v (skinny_qkv_bal_kernel)
+  if (splitk == SK_QKV_BALANCED) {         // 8 slabs of q, 4 of k / v (skinny_qkv_bal_kernel)
     if (wo_heads && nsplit == 1)
-      hipLaunchKernelGGL((dec_attn_kernel<true, 84>), dim3(N_HEAD, (batch + 1) / 2, 1), dim3(ATT_WAVES * 64 * 2), 0, s, kc, vc, slot_meta,
+      hipLaunchKernelGGL((dec_attn_kernel<true, SK_QKV_BALANCED>), dim3(N_HEAD, (batch + 1) / 2, 1), dim3(ATT_WAVES * 64 * 2), 0, s, kc, vc, slot_meta,
                          Tmax, batch, 1, 0, qkv_partial, qkv_bias, xp_out, part_o, part_ml, wo_heads, out_heads);
     else
-      hipLaunchKernelGGL((dec_attn_kernel<false, 84>), dim3(N_HEAD, batch, nsplit), dim3(ATT_WAVES * 64), 0, s, kc, vc, slot_meta, Tmax,
+      hipLaunchKernelGGL((dec_attn_kernel<false, SK_QKV_BALANCED>), dim3(N_HEAD, batch, nsplit), dim3(ATT_WAVES * 64), 0, s, kc, vc, slot_meta, Tmax,
                          batch, nsplit, 0, qkv_partial, qkv_bias, xp_out, part_o, part_ml, (const float*)nullptr, (float*)nullptr);
     return true;
   }

@@ -333,6 +333,11 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
   c->cur_batch = nrows;
   // enough (row, head, split) 8-wave workgroups to put >= 2 on every CU; one split (no combine launch) from 32 rows up
   c->nsplit = std::max(1, std::min(16, 512 / (nrows * N_HEAD)));
+  // 5 .. 16 rows: ONE 8-wave workgroup per CU (256 / (rows x 16) splits, at least 2) -- round 6 sweep at 5 / 8 / 12 / 16 rows x contexts
+  // ~500 / ~1300 (profiles/r06_sb_sweep2.txt): 5 rows 6 -> 3 splits -3.5 %, 8 rows 4 -> 2 splits -3 % / -0.6 % of the AR phase, 12 and 16 rows
+  // stay at 2; one split (the fused out_proj) only pays from 17 rows up
+  if (nrows > SB_ROWS && nrows <= 16) c->nsplit = std::max(2, 256 / (nrows * N_HEAD));
+  if (c->att_nsplit_force > 0) c->nsplit = c->att_nsplit_force;       // measurement switch (tools/gpu_call.sh sb_sweep)
   // the small-batch chain compiles the split counts in (decode.hip): taken only for a combination that is instantiated
   c->sb_chain = false;
   if (c->sb_fuse && nrows <= SB_ROWS) {
@@ -343,7 +348,9 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
     if (c->sb_chain && nrows <= c->sb_qkv_rows) {
       // the fused kernel holds one 8-wave workgroup per CU: 16 heads x rows x splits workgroups must fit the 256 CUs in ONE round,
       // and every workgroup of a head re-reads the head's q slice through L2 -- few splits win (profiles/r04_sb_qkv_ab.log)
-      const int fit[5] = {0, 8, 8, 4, 4};
+      // one row: 16 splits = 256 workgroups (round 6 sweep, profiles/r06_sb_sweep.txt: equal to 8 at contexts ~400 / ~800, -2 % of the AR
+      // phase at ~1300 -- the context share of a workgroup halves while the q slice it re-reads through L2 stays)
+      const int fit[5] = {0, 16, 8, 4, 4};
       const int ns2 = c->sb_qkv_nsplit > 0 ? c->sb_qkv_nsplit : fit[nrows];
       // dec_attn_qkv_kernel addresses the KV arena and its partials by batch ROW and returns when slot_meta[slot].row != row
       // (decode.hip): it is only selected while the launch order is the identity -- checked here, not assumed from `balance` above
@@ -488,7 +495,7 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
     const bool fused = c->fuse_out && c->nsplit == 1;
     {
       ProfScope ps(c, 0);
-      LAUNCH(launch_dec_attn(c->p_qkv, c->qkv_bal ? 84 : SK_QKV, L.in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax, c->slot_meta,
+      LAUNCH(launch_dec_attn(c->p_qkv, c->qkv_bal ? SK_QKV_BALANCED : SK_QKV, L.in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax, c->slot_meta,
                       c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, fused ? L.out_wh : nullptr, c->p_oh, st));
     }
     if (fused) {

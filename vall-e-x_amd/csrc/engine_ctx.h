@@ -142,6 +142,7 @@ struct vx_ctx {
   int gen_stride = 0;
   int cur_batch = 0;
   int nsplit = 1;
+  int att_nsplit_force = 0;        // VX_ATT_NSPLIT=n: context splits of dec_attn on the general chain (0 = 512 / (rows x 16) workgroups rule)
   std::vector<int> h_L;            // prefill lengths of the current micro-batch
 
   // graph

@@ -76,14 +76,18 @@ int gemm_walk_env();
 // private 4 MiB L2, so ids are remapped to give every XCD one contiguous run of the order.  (2) Inside that order tiles come in
 // groups of `gm` row tiles x all column tiles; inside a group the row tile runs fastest (walk >> 8 == 0: the ~32 workgroups an XCD
 // keeps resident cover gm row tiles x 32 / gm column tiles) or the column tile does (walk >> 8 == 1: 32 / tiles_n row tiles x all
-// column tiles).  walk == 0 keeps the kernel's measured default (row-fastest, gm_default).
+// column tiles).  walk == 0: the measured default, see below.
 __device__ __forceinline__ void tile_walk(int wg, int tiles_m, int tiles_n, int gm_default, int walk, int& tm, int& tn) {
   const int nwg = tiles_m * tiles_n;
   {
     const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int GM = walk ? (walk & 255) : gm_default;
+  // walk == 0: N of at most four column tiles (out_proj, linear2: N = 1024) walks column-fastest -- a row tile's column tiles start
+  // back to back and share its A panel while it streams (round 6 sweep, profiles/r06_gemm_walk_*: FETCH_SIZE 691 -> 491 MB per launch on
+  // those shapes, -3..5 % time on the f16x2 kernel); wider N keeps the row-fastest order, which measured best there
+  if (!walk) walk = gm_default | (tiles_n <= 4 ? 256 : 0);
+  const int GM = walk & 255;
   const int per_group = GM * tiles_n;
   const int grp = wg / per_group, in_grp = wg - grp * per_group;
   const int gm0 = grp * GM;
@@ -167,6 +171,10 @@ void launch_attn_full_probe(const float* qkv, float* out, const int* seq_off, co
 void launch_pack_weight(const float* W, int N, int K, float* Wp, int Npad, hipStream_t s);
 // partial[ks][b][n] = sum_{k in slice ks} x[b][k] * W[n][k];  xp is the packed activation image.
 void launch_skinny_gemm(const float* Wp, const float* xp, float* partial, int Npad, int K, int splitk, hipStream_t s);
+// slab counts of the balanced in_proj (skinny_qkv_bal_kernel): q in 8 K slices, k / v in 4.  dec_attn_kernel's SK template parameter
+// carries both as SKQ * 10 + SKV (a plain count <= 10 means the same count for q, k and v: skinny_gemm_kernel with splitk = 4).
+constexpr int SK_QKV_BAL_Q = 8, SK_QKV_BAL_KV = 4;
+constexpr int SK_QKV_BALANCED = SK_QKV_BAL_Q * 10 + SK_QKV_BAL_KV;
 void launch_skinny_qkv_balanced(const float* Wp, const float* xp, float* partial, hipStream_t s);   // 512 workgroups: q in 8 K slices, k / v in 4 (default since round 5)
 // h[b] = (resid? resid[b] : 0) + sum_ks partial[ks][b] + bias ; xp = pack(LN(h)*g+b)   (N = 1024)
 void launch_dec_reduce_ln_pack(const float* partial, int splitk, int npad, const float* bias, const float* resid,

@@ -81,7 +81,14 @@ def _torch_load(path, allow_unsafe_pickle: Optional[bool] = None):
     if allow_unsafe_pickle:
         logging.warning(f"{path}: loading with weights_only=False (explicit opt-in): the file can execute arbitrary code")
         return torch.load(path, map_location="cpu", weights_only=False)
-    safe = [argparse.Namespace, collections.OrderedDict, pathlib.PosixPath, pathlib.PurePosixPath, pathlib.Path]
+    if not hasattr(torch.serialization, "safe_globals"):
+        raise RuntimeError(f"torch {torch.__version__} has no torch.serialization.safe_globals (needs torch >= 2.5): the allow-listed "
+                           "weights-only load of a training checkpoint is not available; pass allow_unsafe_pickle=True for a file you trust")
+    paths = [pathlib.PosixPath, pathlib.PurePosixPath, pathlib.Path]
+    # Python >= 3.13 moved the classes to pathlib._local, so `cls.__module__` no longer matches the "pathlib.PosixPath" a checkpoint
+    # written by an older interpreter names: register them under the historical name as well (torch accepts (obj, "qualified.name"))
+    safe = [argparse.Namespace, collections.OrderedDict] + paths
+    safe += [(cls, f"pathlib.{cls.__name__}") for cls in paths if cls.__module__ != "pathlib"]
     try:
         with torch.serialization.safe_globals(safe):
             return torch.load(path, map_location="cpu", weights_only=True)
