@@ -41,3 +41,41 @@ def test_library_transfers_are_staged_through_the_pinned_ring():
     back = eng.read_tap("roundtrip.big", big.size).reshape(big.shape)
     assert np.array_equal(back, big)
     assert np.array_equal(eng.read_tap("roundtrip.small", 3), small)
+
+
+_WRAP_SCRIPT = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, ".")
+import vallex_amd
+from vallex_amd.models.vallex import VALLE
+from oracle import synth
+m = VALLE(1024, 16, 2, norm_first=True, add_prenet=False, prefix_mode=1, share_embedding=True, nar_scale_factor=1.0, prepend_bos=True,
+          num_quantizers=8, engine_max_new=608, engine_max_prompt=64, engine_max_text=64, engine_max_batch=32)
+m.to("cuda:0").load_state_dict(synth.vallex_state_dict(2, 7, eos_gain=0.0), strict=True)
+m.load_vocos_state_dict(synth.vocos_state_dict(2))
+rng = np.random.default_rng(11)
+codes = [rng.integers(0, 1024, size=(600, 8)).astype(np.int64) for _ in range(32)]      # 32 x 600 frames -> 24.6 MB of audio back
+wav = m.engine.vocos_decode(codes, 2)
+h = hashlib.sha256()
+for w in wav:
+    h.update(np.ascontiguousarray(w, np.float32).tobytes())
+print("DIGEST", h.hexdigest(), sum(w.shape[0] for w in wav))
+"""
+
+
+def test_a_small_ring_wraps_mid_transfer_without_changing_a_byte():
+    """the same Vocos decode of 32 x 600 frames (24.6 MB of audio device -> host, far more than one chunk) with the default 64 MiB
+    ring and with VX_PIN_MB=16 (two chunks: the ring wraps in the middle of the transfer, pending device -> host copies are
+    delivered by the wrap's sync): identical bytes"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for mb in ("64", "16"):
+        r = subprocess.run([sys.executable, "-c", _WRAP_SCRIPT], cwd=root, env=dict(os.environ, VX_PIN_MB=mb), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, (mb, r.stderr[-800:])
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
+    assert outs[0] == outs[1] and outs[0].split()[2] == str(32 * 600 * 320), outs
