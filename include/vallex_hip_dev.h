@@ -43,7 +43,8 @@ int vx_bench_gemm_clock(vx_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t ke
 
 /* Epilogue cross-check of the two f16x2 GEMM kernels on the same operand planes (four waves of 128 x 128 against eight waves of
  * 64 x 128; bit-identical by construction): mode 0 = bias + ReLU + out_planes, 1 = bias + residual through resid_rows (ragged M),
- * 2 = bias + residual in place.  differing / compared = 32-bit words of C (16-bit words of the planes in mode 0).  N % 256 == 0. */
+ * 2 = bias + residual in place; mode + 10: the eight-wave template on 128 x 128 tiles instead of 256 x 256.  differing / compared =
+ * 32-bit words of C (16-bit words of the planes in mode 0).  N % 256 == 0. */
 int vx_bench_gemm_epilogue(vx_ctx* ctx, int32_t M, int32_t N, int32_t K, int32_t mode, int64_t* differing, int64_t* compared);
 
 #ifdef __cplusplus

@@ -215,6 +215,6 @@ def test_f16x2_four_wave_gemm_epilogue_branches_equal_the_eight_wave_kernel_word
     import vallex_amd
     eng = vallex_amd.Engine(num_layers=1, max_batch=1, max_text=8, max_prompt=8, max_new=8, with_vocos=False)
     for (M, N, K) in ((4096, 1024, 1024), (2049, 1024, 4096), (983, 4096, 1024), (257, 256, 64), (19200, 1024, 1024)):
-        for mode in (0, 1, 2):
+        for mode in (0, 1, 2, 10, 11, 12):                     # + 10: the eight-wave template on 128 x 128 tiles (prefill, trimmed layers)
             bad, tot = eng.bench_gemm_epilogue(M, N, K, mode)
             assert bad == 0 and tot >= M * N, (M, N, K, mode, bad, tot)

@@ -40,7 +40,13 @@ template <int V>
 __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                           const int* __restrict__ seq_off,
                                                           const int* __restrict__ seq_len,
-                                                          const int* __restrict__ prefix_len, int nqb) {
+                                                          const int* __restrict__ prefix_len, int nqb,
+                                                          const int* __restrict__ q_first, const int* __restrict__ c_off) {
+  // q_first / c_off (optional, round 6): ROW TRIMMING for the last decoder layer of a NAR stage in the reference-arithmetic mode -- only
+  // the generated frames reach a predict layer (models/vallex.py:672-679), so only the queries [q_first[b], len) of every sequence
+  // are needed.  Query blocks entirely before q_first[b] are skipped and the output is written COMPACTED: sequence-local query qi
+  // lands in row c_off[b] + qi - q_first[b] of `out`.  Keys / values are all of the sequence and a kept query sees the same tiles
+  // in the same order as without trimming: the same bits (the scheme of attn_full_h2.hip).
   __shared__ __attribute__((aligned(16))) float Ks[2][KT * K_LD];
   __shared__ __attribute__((aligned(16))) float Vs[2][KT * V_LD];
 
@@ -54,6 +60,8 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
   const int b = u / N_HEAD, h = u - b * N_HEAD, q0 = (rem >> 3) * QB;
   const int len = seq_len[b];
   if (q0 >= len) return;
+  const int qf = q_first ? q_first[b] : 0;
+  if (q0 + QB <= qf) return;                                    // no query of this block is needed
   const long row0 = seq_off[b];
   const int S = prefix_len ? prefix_len[b] : 0x7fffffff;       // keys < S are visible to everyone
   const bool causal = prefix_len != nullptr;   // only narrows the block's key range below
@@ -215,9 +223,10 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  if (qi < len) {
+  if (qi < len && qi >= qf) {
     const float inv = 1.0f / l_tot;
-    float* op = out + (row0 + qi) * (long)D_MODEL + h * D_HEAD + 4 * hi;
+    const long orow = c_off ? (long)c_off[b] + (qi - qf) : row0 + qi;
+    float* op = out + orow * (long)D_MODEL + h * D_HEAD + 4 * hi;
 #pragma unroll
     for (int half = 0; half < 2; ++half)
 #pragma unroll
@@ -231,11 +240,11 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
 }
 
 void launch_attn_full(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
-                      int batch, int max_len, hipStream_t s) {
+                      int batch, int max_len, hipStream_t s, const int* q_first, const int* c_off) {
   if (batch <= 0 || max_len <= 0) return;
   const int nqb = (max_len + QB - 1) / QB;                   // batch * N_HEAD is a multiple of 8 (16 heads)
   hipLaunchKernelGGL(attn_full_kernel<0>, dim3(nqb * N_HEAD * batch), dim3(256), 0, s, qkv, out, seq_off, seq_len,
-                     prefix_len, nqb);
+                     prefix_len, nqb, q_first, c_off);
 }
 
 #ifdef VX_DEV_PROBES   // timing probes: tools-only build (vall-e-x_amd/_build.py --dev), never in the product library
@@ -243,9 +252,9 @@ void launch_attn_full_probe(const float* qkv, float* out, const int* seq_off, co
                             int batch, int max_len, int variant, hipStream_t s) {
   const int nqb = (max_len + QB - 1) / QB;
   const dim3 grid(nqb * N_HEAD * batch), block(256);
-  if (variant == 1) hipLaunchKernelGGL(attn_full_kernel<1>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
-  else if (variant == 2) hipLaunchKernelGGL(attn_full_kernel<2>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
-  else hipLaunchKernelGGL(attn_full_kernel<3>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb);
+  if (variant == 1) hipLaunchKernelGGL(attn_full_kernel<1>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, (const int*)nullptr, (const int*)nullptr);
+  else if (variant == 2) hipLaunchKernelGGL(attn_full_kernel<2>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, (const int*)nullptr, (const int*)nullptr);
+  else hipLaunchKernelGGL(attn_full_kernel<3>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, (const int*)nullptr, (const int*)nullptr);
 }
 
 #endif

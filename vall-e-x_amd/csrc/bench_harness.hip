@@ -427,6 +427,9 @@ int vx_bench_attn(vx_ctx* c, int32_t batch, int32_t len, int32_t causal, int32_t
 // every fp32 result and every plane half-word must be IDENTICAL: returns the number of differing 32-bit words of C (modes 1, 2) or
 // 16-bit words of the planes (mode 0), and how many words were compared.
 int vx_bench_gemm_epilogue(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t mode, int64_t* differing, int64_t* compared) {
+  // mode + 10: the eight-wave template on 128 x 128 tiles (the prefill / trimmed-layer instance) against the four-wave kernel
+  const bool small_tiles = mode >= 10;
+  if (small_tiles) mode -= 10;
   if (!c || M <= 0 || N <= 0 || K < 64 || K % 32 || N % 256 || mode < 0 || mode > 2 || !differing || !compared) return VX_EINVAL;
   HIPCHK(hipSetDevice(c->dev));
   const long a_pl = h2_plane(M, K, H2_TILE_A), w_pl = h2_plane(N, K, H2_TILE_W), o_pl = h2_plane(M, N, H2_TILE_A);
@@ -485,7 +488,7 @@ int vx_bench_gemm_epilogue(vx_ctx* c, int32_t M, int32_t N, int32_t K, int32_t m
   else { g.act = ACT_NONE; g.resid = resid; g.ldr = N; if (mode == 1) g.resid_rows = rows; }
   GemmX3Args g0 = g, g1 = g;
   if (mode == 0) { g0.out_planes = P0; g1.out_planes = P1; } else { g0.C = C0; g1.C = C1; }
-  launch_gemm_f16x2(g0, c->stream, 256);        // eight waves of 64 x 128
+  launch_gemm_f16x2(g0, c->stream, small_tiles ? -128 : 256);        // eight-wave template: 128 x 128 tiles / 256 x 256 tiles (64 x 128 per wave)
   launch_gemm_f16x2(g1, c->stream, 257);        // four waves of 128 x 128
   SYNC();
   TRY(hipGetLastError());

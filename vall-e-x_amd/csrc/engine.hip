@@ -89,10 +89,10 @@ int tap_store(vx_ctx* c, const std::string& name, const float* src, size_t n) {
 
 // ---- dense helpers -----------------------------------------------------------------------------------------
 void gemm(vx_ctx* c, const float* A, int lda, const float* Wt, int ldw, const float* bias, const float* resid, int ldr,
-          const float* colscale, float* C, int ldc, long M, int N, int K, int act, const int* gather, int cls) {
+          const float* colscale, float* C, int ldc, long M, int N, int K, int act, const int* gather, int cls, const int* resid_rows) {
   GemmArgs g{};
   g.A = A; g.lda = lda; g.W = Wt; g.ldw = ldw; g.bias = bias; g.resid = resid; g.ldr = ldr; g.colscale = colscale;
-  g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.act = act; g.row_gather = gather;
+  g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K; g.act = act; g.row_gather = gather; g.resid_rows = resid_rows;
   ProfScope ps(c, cls);               // class 2 = transformer projections (proj), 4 = the fp32 GEMMs of Vocos / EnCodec
   if (c->prof_on) c->prof[cls].bytes += 2.0 * (double)M * N * K;      // flops for this class
   launch_gemm_f32(g, c->stream);
@@ -105,7 +105,7 @@ void proj(vx_ctx* c, const float* A, int lda, const float* Wf, const unsigned sh
           const float* resid, int ldr, float* C, int ldc, long M, int N, int K, int act, const int* gather = nullptr,
           const unsigned short* a_pre = nullptr, unsigned short* out_pl = nullptr, const int* resid_rows = nullptr) {
   if (c->gemm_mode == 2 || !W3) {
-    gemm(c, A, lda, Wf, K, bias, resid, ldr, nullptr, C, ldc, M, N, K, act, gather, 2);
+    gemm(c, A, lda, Wf, K, bias, resid, ldr, nullptr, C, ldc, M, N, K, act, gather, 2, resid_rows);
     return;
   }
   const long a_plane = c->gemm_mode == 0 ? h2_plane(M, K, H2_TILE_A) : (long)M * K;
@@ -154,7 +154,26 @@ int full_layer(vx_ctx* c, const LayerW& L, long M, const int* seq_off, const int
        pl ? c->fa3 : nullptr);
   if (kcl) launch_kv_scatter(c->fqkv, row_b, row_t, (int)M, kcl, vcl, c->Tmax, c->stream);
   const bool att_pl = pl && c->attn_x3;
-  if (tr) {                                        // caller guarantees f16x2 projections + f16x2 attention
+  if (tr && !pl) {
+    // reference arithmetic (fp32 projections + fp32 attention, round 6): the same trimming on fp32 rows.  The compacted residual
+    // stream lives in the QKV buffer, which is free once the attention has read it (stream order); fatt / fxn / fffn hold the
+    // compacted attention output, normalised rows and hidden activations.  gemm_f32 reads the residual of out_proj through the row
+    // map (GemmArgs.resid_rows); every kept row goes through the arithmetic it would see untrimmed.
+    float* xc = c->fqkv;
+    {
+      ProfScope ps(c, 3);
+      if (c->prof_on) c->prof[3].bytes += tr->attn_flops;
+      launch_attn_full(c->fqkv, c->fatt, seq_off, seq_len, prefix_len, batch, max_len, c->stream, tr->q_first, tr->c_off);
+    }
+    proj(c, c->fatt, D_MODEL, L.out_w, L.out_w3, L.out_b, c->fx, D_MODEL, xc, D_MODEL, tr->Mc, D_MODEL, D_MODEL, ACT_NONE, nullptr, nullptr,
+         nullptr, tr->rows);
+    launch_layernorm(xc, D_MODEL, c->fxn, D_MODEL, (int)tr->Mc, D_MODEL, LN_EPS, L.n2_w, L.n2_b, ada2, ada2 ? ada2 + D_MODEL : nullptr,
+                     c->stream);
+    proj(c, c->fxn, D_MODEL, L.l1_w, L.l1_w3, L.l1_b, nullptr, 0, c->fffn, D_FF, tr->Mc, D_FF, D_MODEL, ACT_RELU);
+    proj(c, c->fffn, D_FF, L.l2_w, L.l2_w3, L.l2_b, xc, D_MODEL, xc, D_MODEL, tr->Mc, D_MODEL, D_FF, ACT_NONE);
+    return VX_OK;
+  }
+  if (tr) {                                        // f16x2 projections + f16x2 attention
     const long plc = h2_plane(tr->Mc, D_MODEL, H2_TILE_A);
     {
       ProfScope ps(c, 3);
@@ -728,7 +747,10 @@ int nar_generate_once(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::v
                           c->stream);
     const float* ada = c->ada + (size_t)st * nnorm * 2 * D_MODEL;
     // the last layer only has to produce the generated rows (struct Trim); the per-layer taps want every row
-    const bool trim = c->nar_trim && c->gemm_mode == 0 && c->attn_x3 && c->attn_h2 && !c->cfg.debug_taps;
+    // f16x2 projections + f16x2 attention, or the reference arithmetic (fp32 projections + fp32 attention); the mixed modes of the
+    // VX_GEMM_* / VX_ATTN_* switches and bf16x3 run every row
+    const bool trim_h2 = c->gemm_mode == 0 && c->attn_x3 && c->attn_h2, trim_f32 = c->gemm_mode == 2 && !c->attn_x3;
+    const bool trim = c->nar_trim && (trim_h2 || trim_f32) && !c->cfg.debug_taps;
     const Trim tr{sumT, mb.dev(o_qf), mb.dev(o_co), mb.dev(o_gr), trim_attn_flops};
     for (int l = 0; l < NL; ++l) {
       if (int e = full_layer(c, c->nar[l], M, mb.dev(o_off), mb.dev(o_len), nullptr, nb, max_len,
@@ -744,7 +766,12 @@ int nar_generate_once(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::v
     const float* adaf = ada + (size_t)(2 * NL) * 2 * D_MODEL;
     char nm[64];
     snprintf(nm, sizeof nm, "nar_predict_layers.%d.weight", st);
-    if (trim) {
+    if (trim && trim_f32) {
+      // the compacted residual stream (in the QKV buffer, full_layer) holds exactly the rows the predict layer reads: no gather
+      launch_layernorm(c->fqkv, D_MODEL, c->fxn, D_MODEL, (int)sumT, D_MODEL, LN_EPS, W(c, "nar_decoder.norm.norm.weight"),
+                       W(c, "nar_decoder.norm.norm.bias"), adaf, adaf + D_MODEL, c->stream);
+      proj(c, c->fxn, D_MODEL, W(c, nm), c->pred_w3[st], nullptr, nullptr, 0, c->flogits, AUDIO_VOCAB, sumT, AUDIO_VOCAB, D_MODEL, ACT_NONE);
+    } else if (trim) {
       // the compacted residual stream (fxn) holds exactly the rows the predict layer reads: the final norm writes the GEMM's
       // operand planes itself (bit-identical to a split of its fp32 result), no gather, no split pass
       launch_layernorm(c->fxn, D_MODEL, nullptr, D_MODEL, (int)sumT, D_MODEL, LN_EPS, W(c, "nar_decoder.norm.norm.weight"),

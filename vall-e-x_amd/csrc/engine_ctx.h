@@ -269,7 +269,8 @@ struct MetaBuilder {
 int tap_store(vx_ctx* c, const std::string& name, const float* src, size_t n);
 // C = resid + colscale * act(A W^T + bias) on the fp32 MFMA (cls: profiling class, 2 = transformer projections, 4 = vocoders)
 void gemm(vx_ctx* c, const float* A, int lda, const float* Wt, int ldw, const float* bias, const float* resid, int ldr,
-          const float* colscale, float* C, int ldc, long M, int N, int K, int act, const int* gather = nullptr, int cls = 4);
+          const float* colscale, float* C, int ldc, long M, int N, int K, int act, const int* gather = nullptr, int cls = 4,
+          const int* resid_rows = nullptr);
 bool range_guarded(const vx_ctx* c);
 int ensure_f32_buffers(vx_ctx* c);
 int take_range_flag(vx_ctx* c, bool* raised);

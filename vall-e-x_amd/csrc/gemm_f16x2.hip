@@ -304,13 +304,40 @@ __global__ __launch_bounds__(TM * 2, (TM == 256 || NST == 4) ? 1 : 2) void gemm_
   // activations nor a split pass.  The 32 columns of a (jn) block are exactly one K tile of the consumer; lanes l and l ^ 32 hold
   // complementary 4-column halves of each 8-column group, so they trade halves (one ds_bpermute per word) and every lane stores
   // 16 contiguous bytes per plane.  Same conversions as split2h_kernel => bit-identical planes.
+  // Round 6: no dependent load -> wait -> use chain per 4 columns any more (the lesson of the four-wave kernel, profiles/
+  // r05_gemm_w128_workload_ab.log, carried to this one: it still serves the 128 x 128 tiles of the prefill and of the trimmed last
+  // layers): the four bias and the four residual vectors of block (i, jn + 1) are requested before block (i, jn) is processed, and
+  // the residual row of a lane's two output rows (through resid_rows for compacted row sets) is looked up once.  Same values, same
+  // operations per element: bit-identical output.
+  const bool has_bias = g.bias != nullptr, has_res = g.resid != nullptr;
+  long mrow[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int m = m0 + wm * 64 + i * 32 + l31;
-    if (m >= g.M) continue;
-    const int mr = (g.resid && g.resid_rows) ? g.resid_rows[m] : m;      // residual row (compacted row sets read it through a map)
+    int m = m0 + wm * 64 + i * 32 + l31;
+    m = m < g.M ? m : g.M - 1;
+    mrow[i] = (has_res && g.resid_rows) ? g.resid_rows[m] : m;
+  }
+  auto load_blk = [&](int t, f32x4 (&bb)[4], f32x4 (&rr)[4]) {       // block t = NJ i + jn
+    const int i = t / NJ, jn = t % NJ;
 #pragma unroll
-    for (int jn = 0; jn < NJ; ++jn) {
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int n = n0 + wn * (TN / 2) + jn * 32 + 8 * g4 + 4 * hi;
+      const bool in = n < g.N;                                       // N % 4 == 0: a float4 is all in or all out
+      bb[g4] = (has_bias && in) ? *reinterpret_cast<const f32x4*>(g.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      rr[g4] = (has_res && in) ? *reinterpret_cast<const f32x4*>(g.resid + mrow[i] * g.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  f32x4 bbA[4], rrA[4], bbB[4], rrB[4];
+  load_blk(0, bbA, rrA);
+#pragma unroll
+  for (int t = 0; t < 2 * NJ; ++t) {
+    const int i = t / NJ, jn = t % NJ;
+    const int m = m0 + wm * 64 + i * 32 + l31;
+    f32x4 (&bbc)[4] = (t & 1) ? bbB : bbA;
+    f32x4 (&rrc)[4] = (t & 1) ? rrB : rrA;
+    if (t + 1 < 2 * NJ) load_blk(t + 1, (t & 1) ? bbA : bbB, (t & 1) ? rrA : rrB);
+    if (m >= g.M) continue;
+    {
       unsigned hw[4][2], tw[4][2];                               // [g4][pair]: packed fp16 heads / scaled tails (planes mode)
       bool bad = false;
 #pragma unroll
@@ -320,19 +347,17 @@ __global__ __launch_bounds__(TM * 2, (TM == 256 || NST == 4) ? 1 : 2) void gemm_
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][jn][4 * g4 + e] * g.descale;
-        if (g.bias) {
-          const f32x4 bi = *reinterpret_cast<const f32x4*>(g.bias + n);
+        if (has_bias) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bi[e];
+          for (int e = 0; e < 4; ++e) v[e] += bbc[g4][e];
         }
         if (g.act == ACT_RELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        if (g.resid) {
-          const f32x4 rr = *reinterpret_cast<const f32x4*>(g.resid + (long)mr * g.ldr + n);
+        if (has_res) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = rr[e] + v[e];
+          for (int e = 0; e < 4; ++e) v[e] = rrc[g4][e] + v[e];
         }
         if (!g.out_planes) {
           *reinterpret_cast<f32x4*>(g.C + (long)m * g.ldc + n) = v;

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
           for (int e = 0; e < 4; ++e) v[e] = v[e] * cs[e];
         }
         if (g.resid) {
-          const f32x4 rr = *reinterpret_cast<const f32x4*>(g.resid + (long)m * g.ldr + n);
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(g.resid + (long)(g.resid_rows ? g.resid_rows[m] : m) * g.ldr + n);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = rr[e] + v[e];
         }
@@ -303,11 +303,18 @@ __global__ __launch_bounds__(TM * 2, TM == 256 ? 1 : 2) void gemm_f32_dma_kernel
     if (has_cs && n < g.N) *reinterpret_cast<f32x4*>(lcs + tid * 4) = *reinterpret_cast<const f32x4*>(g.colscale + n);
   }
   __syncthreads();
-  auto load_rr = [&](int t, f32x4 (&rr)[4]) {       // block t = NJ i + jn
-    const int i = t / NJ, jn = t % NJ;
+  // residual row of this lane's two output rows (i = 0, 1): the row itself, or through the row map of a compacted row set
+  // (resid_rows, the trimmed last NAR layer) -- looked up ONCE here, not in front of every residual vector
+  long rrow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
     int m = m0 + wm * 64 + i * 32 + l31;
     m = m < g.M ? m : g.M - 1;
-    const float* rp = g.resid + (long)m * g.ldr + n0 + wn * (TN / 2) + jn * 32 + 4 * hi;
+    rrow[i] = (has_res && g.resid_rows) ? g.resid_rows[m] : m;
+  }
+  auto load_rr = [&](int t, f32x4 (&rr)[4]) {       // block t = NJ i + jn
+    const int i = t / NJ, jn = t % NJ;
+    const float* rp = g.resid + rrow[i] * g.ldr + n0 + wn * (TN / 2) + jn * 32 + 4 * hi;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       const int n = n0 + wn * (TN / 2) + jn * 32 + 8 * g4 + 4 * hi;

@@ -36,6 +36,7 @@ struct GemmArgs {
   int act;
   const int* row_gather;    // optional: A row index per output row (null = identity)
   int walk;                 // tile order override (tile_walk below): 0 = the kernel's own; else group depth | column-fastest << 8
+  const int* resid_rows;    // optional: row of `resid` read for output row m (null = m): compacted row sets (trimmed last NAR layer)
 };
 void launch_gemm_f32(const GemmArgs& g, hipStream_t s, int variant = 0);   // variant: gemm_f32.hip (0 = product choice)
 
@@ -148,7 +149,7 @@ void launch_gemv(const float* W, const float* e, const float* b, float* out, int
 // (text rows see text only; audio rows see all text + causal audio, models/vallex.py:535-549), or null for
 // the unmasked NAR attention.
 void launch_attn_full(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
-                      int batch, int max_len, hipStream_t s);
+                      int batch, int max_len, hipStream_t s, const int* q_first = nullptr, const int* c_off = nullptr);
 
 // bf16x3 version (attn_full_x3.hip), the product path; variant 0 = product (1-5 = timing probes, VX_DEV_PROBES builds only)
 // planes (optional; out may then be null): write the result as the f16x2 A planes of out_proj (tile-major, K = 1024)
