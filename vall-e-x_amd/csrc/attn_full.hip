@@ -15,6 +15,8 @@
 //   O^T += V^T . P^T   32 MFMAs  (A = V columns from LDS via ds_read_b32, B = the P registers as they are)
 // The C-layout row map (r&3)+8*(r>>2)+4*(lane>>5) of S^T is used directly as the key order of the second
 // contraction, so P never moves between lanes.
+#include <stdlib.h>
+
 #include "vx_common.h"
 
 namespace vx {
@@ -36,7 +38,11 @@ __device__ __forceinline__ float exp_bf(float x) {
 
 // V = 0 product kernel.  Timing probes (tools/attn_bench.py, results meaningless): V = 1 no K/V staging after the first two
 // tiles; V = 2 no MFMAs; V = 3 no softmax arithmetic.
-template <int V>
+// NB: LDS buffers of the K / V tile ring.  2 = the kernel of rounds 1-5 (two barriers per tile: everyone done reading `cur` | tile
+// t + 2 written into it).  3 (round 6, as attn_full_h2.hip always had it): tile t + 2 goes into the THIRD buffer -- the one tile t - 1
+// occupied, which every wave left before the barrier that ended iteration t - 1 -- so ONE barrier per tile is enough.  Same
+// operations on the same values in the same order: bit-identical output.
+template <int V, int NB>
 __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                           const int* __restrict__ seq_off,
                                                           const int* __restrict__ seq_len,
@@ -47,8 +53,8 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
   // are needed.  Query blocks entirely before q_first[b] are skipped and the output is written COMPACTED: sequence-local query qi
   // lands in row c_off[b] + qi - q_first[b] of `out`.  Keys / values are all of the sequence and a kept query sees the same tiles
   // in the same order as without trimming: the same bits (the scheme of attn_full_h2.hip).
-  __shared__ __attribute__((aligned(16))) float Ks[2][KT * K_LD];
-  __shared__ __attribute__((aligned(16))) float Vs[2][KT * V_LD];
+  __shared__ __attribute__((aligned(16))) float Ks[NB][KT * K_LD];
+  __shared__ __attribute__((aligned(16))) float Vs[NB][KT * V_LD];
 
   // XCD-aware work order.  Workgroup ids are dealt round-robin to the 8 XCDs (id % 8), each with a private L2, and the
   // K/V of one (sequence, head) are re-read by every query block of that unit.  Units are therefore dealt 8 at a time
@@ -135,15 +141,18 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
   const int ntiles = (kv_end + KT - 1) / KT;
   issue(0);
   stage_write(0);
-  __syncthreads();
+  if (NB == 2) __syncthreads();
   if (1 < ntiles) issue(KT);
-  f32x16 s_cur = qk(0);
+  f32x16 s_cur;
+  if (NB == 2) s_cur = qk(0);
   if (1 < ntiles) stage_write(1);
   __syncthreads();
   if (2 < ntiles) issue(2 * KT);
+  if (NB == 3) s_cur = qk(0);
 
   for (int t = 0; t < ntiles; ++t) {
-    const int k0 = t * KT, cur = t & 1, nxt = cur ^ 1;
+    // buffers of tile t (its V is read in phase 2), of tile t + 1 (its K in phase 1) and the one tile t + 2 is written into
+    const int k0 = t * KT, cur = NB == 3 ? t % 3 : (t & 1), nxt = NB == 3 ? (t + 1) % 3 : (cur ^ 1), wr = NB == 3 ? (t + 2) % 3 : cur;
     // ---- phase 1: QK^T of tile t+1 (32 MFMAs) with the softmax of tile t threaded through it.
     // In-order issue + dependent MFMA chains mean VALU work only overlaps the matrix pipe if it physically sits between
     // the MFMAs, so the tile is cut into 16 steps of [2 MFMAs | one slice of the softmax], fenced by sched_barrier(0).
@@ -216,8 +225,8 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) s_cur[r] = sA[r];
-    __syncthreads();                                           // everyone is done reading buffer `cur`
-    if (V != 1 && t + 2 < ntiles) stage_write(cur);            // registers hold tile t+2
+    if (NB == 2) __syncthreads();                              // two buffers: everyone is done reading buffer `cur` (= wr)
+    if (V != 1 && t + 2 < ntiles) stage_write(wr);             // registers hold tile t+2
     __syncthreads();
     if (V != 1 && t + 3 < ntiles) issue((t + 3) * KT);
   }
@@ -240,11 +249,18 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
 }
 
 void launch_attn_full(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
-                      int batch, int max_len, hipStream_t s, const int* q_first, const int* c_off) {
+                      int batch, int max_len, hipStream_t s, const int* q_first, const int* c_off, int nbuf) {
   if (batch <= 0 || max_len <= 0) return;
   const int nqb = (max_len + QB - 1) / QB;                   // batch * N_HEAD is a multiple of 8 (16 heads)
-  hipLaunchKernelGGL(attn_full_kernel<0>, dim3(nqb * N_HEAD * batch), dim3(256), 0, s, qkv, out, seq_off, seq_len,
-                     prefix_len, nqb, q_first, c_off);
+  // nbuf 0: the product's choice (three LDS buffers, one barrier per tile; VX_ATTN_F32_NBUF=2 in the environment: the two-buffer kernel)
+  static const int env_nb = [] { const char* e = getenv("VX_ATTN_F32_NBUF"); return (e && e[0] == '2') ? 2 : 3; }();
+  if (nbuf == 0) nbuf = env_nb;
+  if (nbuf == 2)
+    hipLaunchKernelGGL((attn_full_kernel<0, 2>), dim3(nqb * N_HEAD * batch), dim3(256), 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb,
+                       q_first, c_off);
+  else
+    hipLaunchKernelGGL((attn_full_kernel<0, 3>), dim3(nqb * N_HEAD * batch), dim3(256), 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb,
+                       q_first, c_off);
 }
 
 #ifdef VX_DEV_PROBES   // timing probes: tools-only build (vall-e-x_amd/_build.py --dev), never in the product library
@@ -252,9 +268,9 @@ void launch_attn_full_probe(const float* qkv, float* out, const int* seq_off, co
                             int batch, int max_len, int variant, hipStream_t s) {
   const int nqb = (max_len + QB - 1) / QB;
   const dim3 grid(nqb * N_HEAD * batch), block(256);
-  if (variant == 1) hipLaunchKernelGGL(attn_full_kernel<1>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, (const int*)nullptr, (const int*)nullptr);
-  else if (variant == 2) hipLaunchKernelGGL(attn_full_kernel<2>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, (const int*)nullptr, (const int*)nullptr);
-  else hipLaunchKernelGGL(attn_full_kernel<3>, grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, (const int*)nullptr, (const int*)nullptr);
+  if (variant == 1) hipLaunchKernelGGL((attn_full_kernel<1, 2>), grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, (const int*)nullptr, (const int*)nullptr);
+  else if (variant == 2) hipLaunchKernelGGL((attn_full_kernel<2, 2>), grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, (const int*)nullptr, (const int*)nullptr);
+  else hipLaunchKernelGGL((attn_full_kernel<3, 2>), grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, (const int*)nullptr, (const int*)nullptr);
 }
 
 #endif

@@ -374,6 +374,8 @@ int vx_bench_attn(vx_ctx* c, int32_t batch, int32_t len, int32_t causal, int32_t
   const int* pre = causal ? meta + 2 * batch : nullptr;
   auto run = [&]() {
     if (variant == 0) launch_attn_full(qkv, out, meta, meta + batch, pre, batch, len, c->stream);
+    else if (variant == 8 || variant == 9)          // 8 / 9: the fp32 kernel with two / three LDS buffers forced (round-6 A/B)
+      launch_attn_full(qkv, out, meta, meta + batch, pre, batch, len, c->stream, nullptr, nullptr, variant - 6);
 #ifdef VX_DEV_PROBES
     else if (variant < 10) launch_attn_full_probe(qkv, out, meta, meta + batch, pre, batch, len, variant, c->stream);
 #else
@@ -398,8 +400,8 @@ int vx_bench_attn(vx_ctx* c, int32_t batch, int32_t len, int32_t causal, int32_t
   *avg_us = (double)ms * 1e3 / reps;
   if (max_diff) {
     *max_diff = -1.0;
-    if (variant == 0 || variant == 10 || (variant >= 20 && variant <= 23)) {
-      launch_attn_full(qkv, ref, meta, meta + batch, pre, batch, len, c->stream);
+    if (variant == 0 || variant == 8 || variant == 9 || variant == 10 || (variant >= 20 && variant <= 23)) {
+      launch_attn_full(qkv, ref, meta, meta + batch, pre, batch, len, c->stream, nullptr, nullptr, 2);      // reference: the two-buffer fp32 kernel
       SYNC();
       std::vector<float> ho((size_t)M * D_MODEL), hr((size_t)M * D_MODEL);
       D2H(ho.data(), out, ho.size() * 4); SYNC();

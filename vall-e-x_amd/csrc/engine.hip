@@ -127,11 +127,11 @@ void proj(vx_ctx* c, const float* A, int lda, const float* Wf, const unsigned sh
   else launch_gemm_bf16x3(g, c->stream);
 }
 
-// Row trimming of the LAST decoder layer of a NAR stage (f16x2 mode): only the generated frames of every sequence reach a predict
+// Row trimming of the LAST decoder layer of a NAR stage (f16x2 mode, and since round 6 the reference-arithmetic fp32 mode): only the generated frames of every sequence reach a predict
 // layer (models/vallex.py:672-679), so behind the K / V projection -- which attention needs for ALL rows -- the layer only has to
 // produce those rows: attention queries, out_proj, norm2 and the FFN run on the Mc = sum T_b compacted rows.  Every op of the
 // block treats rows independently, so each kept row goes through exactly the arithmetic it would see untrimmed: same ids, same
-// logits, bit for bit.  The compacted residual stream lives in c->fxn (unused in f16x2 mode otherwise).
+// logits, bit for bit.  The compacted residual stream lives in c->fxn (f16x2 mode: unused otherwise) or in the QKV buffer (fp32 mode).
 struct Trim {
   long Mc;               // kept rows
   const int* q_first;    // [batch] first kept sequence-local row (S + Tp)

@@ -149,7 +149,7 @@ void launch_gemv(const float* W, const float* e, const float* b, float* out, int
 // (text rows see text only; audio rows see all text + causal audio, models/vallex.py:535-549), or null for
 // the unmasked NAR attention.
 void launch_attn_full(const float* qkv, float* out, const int* seq_off, const int* seq_len, const int* prefix_len,
-                      int batch, int max_len, hipStream_t s, const int* q_first = nullptr, const int* c_off = nullptr);
+                      int batch, int max_len, hipStream_t s, const int* q_first = nullptr, const int* c_off = nullptr, int nbuf = 0);
 
 // bf16x3 version (attn_full_x3.hip), the product path; variant 0 = product (1-5 = timing probes, VX_DEV_PROBES builds only)
 // planes (optional; out may then be null): write the result as the f16x2 A planes of out_proj (tile-major, K = 1024)
