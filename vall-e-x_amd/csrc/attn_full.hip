@@ -38,8 +38,8 @@ __device__ __forceinline__ float exp_bf(float x) {
 
 // V = 0 product kernel.  Timing probes (tools/attn_bench.py, results meaningless): V = 1 no K/V staging after the first two
 // tiles; V = 2 no MFMAs; V = 3 no softmax arithmetic.
-// NB: LDS buffers of the K / V tile ring.  2 = the kernel of rounds 1-5 (two barriers per tile: everyone done reading `cur` | tile
-// t + 2 written into it).  3 (round 6, as attn_full_h2.hip always had it): tile t + 2 goes into the THIRD buffer -- the one tile t - 1
+// NB: LDS buffers of the K / V tile ring.  2 = the product (two barriers per tile: everyone done reading `cur` | tile
+// t + 2 written into it).  3 (round-6 experiment, as attn_full_h2.hip always had it; measured null, see launch_attn_full): tile t + 2 goes into the THIRD buffer -- the one tile t - 1
 // occupied, which every wave left before the barrier that ended iteration t - 1 -- so ONE barrier per tile is enough.  Same
 // operations on the same values in the same order: bit-identical output.
 template <int V, int NB>
@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
                                                           const int* __restrict__ seq_off,
                                                           const int* __restrict__ seq_len,
                                                           const int* __restrict__ prefix_len, int nqb,
-                                                          const int* __restrict__ q_first, const int* __restrict__ c_off) {
+                                                          const int* __restrict__ q_first, const int* __restrict__ c_off,
+                                                          int mask_all) {
   // q_first / c_off (optional, round 6): ROW TRIMMING for the last decoder layer of a NAR stage in the reference-arithmetic mode -- only
   // the generated frames reach a predict layer (models/vallex.py:672-679), so only the queries [q_first[b], len) of every sequence
   // are needed.  Query blocks entirely before q_first[b] are skipped and the output is written COMPACTED: sequence-local query qi
@@ -150,6 +151,15 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
   if (2 < ntiles) issue(2 * KT);
   if (NB == 3) s_cur = qk(0);
 
+  // Round 6: the visibility mask costs ~100 of the ~500 VALU instructions of a tile's softmax and is the identity on every tile that
+  // lies entirely inside what ALL 32 queries of the wave may see: keys below `len`, and -- prefix-LM mask of the prefill -- below S when
+  // the wave holds text queries, below its first query + 1 when it holds audio queries only.  The NAR stages (no mask) need it on
+  // the last, ragged tile of a sequence only.  A wave-uniform test per tile skips it (the h2 kernel applies its mask the same way).
+  const int q_w0 = q0 + wid * 32;
+  const int lim_min = causal ? (q_w0 < S ? S : q_w0 + 1) : 0x7fffffff;
+  // (mask_all: VX_ATTN_F32_MASKALL=1, the kernel of rounds 1-5 for A/B -- the mask on every tile)
+  const int full_keys = mask_all ? 0 : __builtin_amdgcn_readfirstlane(len < lim_min ? len : lim_min);   // tiles ending at or below: no mask
+
   for (int t = 0; t < ntiles; ++t) {
     // buffers of tile t (its V is read in phase 2), of tile t + 1 (its K in phase 1) and the one tile t + 2 is written into
     const int k0 = t * KT, cur = NB == 3 ? t % 3 : (t & 1), nxt = NB == 3 ? (t + 1) % 3 : (cur ^ 1), wr = NB == 3 ? (t + 2) % 3 : cur;
@@ -178,7 +188,8 @@ __global__ __launch_bounds__(256, 2) void attn_full_kernel(const float* __restri
       }
       if (V == 3) {
         // probe: no softmax work at all
-      } else if (i < 4) {                                      // steps 0-3: visibility mask, 4 keys per step
+      } else if (i < 4) {                                      // steps 0-3: visibility mask, 4 keys per step (uniform skip: see above)
+        if (k0 + KT > full_keys)
 #pragma unroll
         for (int r = 4 * i; r < 4 * i + 4; ++r) {
           const int kj = k0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -252,15 +263,18 @@ void launch_attn_full(const float* qkv, float* out, const int* seq_off, const in
                       int batch, int max_len, hipStream_t s, const int* q_first, const int* c_off, int nbuf) {
   if (batch <= 0 || max_len <= 0) return;
   const int nqb = (max_len + QB - 1) / QB;                   // batch * N_HEAD is a multiple of 8 (16 heads)
-  // nbuf 0: the product's choice (three LDS buffers, one barrier per tile; VX_ATTN_F32_NBUF=2 in the environment: the two-buffer kernel)
-  static const int env_nb = [] { const char* e = getenv("VX_ATTN_F32_NBUF"); return (e && e[0] == '2') ? 2 : 3; }();
+  // nbuf 0: the product's choice = two LDS buffers.  The three-buffer / one-barrier variant measured -0.7 % at the NAR shape, +0.4 % at the
+  // prefill shape and nothing end to end (profiles/r06_attn_f32_nbuf_ab.log: NAR 614.7 / 615.2 vs 615.5 / 616.7 ms): below the 3 % bar, so
+  // the kernel of rounds 1-5 stays; VX_ATTN_F32_NBUF=3 selects the variant (bit-identical) for A/B
+  static const int env_nb = [] { const char* e = getenv("VX_ATTN_F32_NBUF"); return (e && e[0] == '3') ? 3 : 2; }();
   if (nbuf == 0) nbuf = env_nb;
+  static const int mask_all = [] { const char* e = getenv("VX_ATTN_F32_MASKALL"); return (e && e[0] == '1') ? 1 : 0; }();
   if (nbuf == 2)
     hipLaunchKernelGGL((attn_full_kernel<0, 2>), dim3(nqb * N_HEAD * batch), dim3(256), 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb,
-                       q_first, c_off);
+                       q_first, c_off, mask_all);
   else
     hipLaunchKernelGGL((attn_full_kernel<0, 3>), dim3(nqb * N_HEAD * batch), dim3(256), 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb,
-                       q_first, c_off);
+                       q_first, c_off, mask_all);
 }
 
 #ifdef VX_DEV_PROBES   // timing probes: tools-only build (vall-e-x_amd/_build.py --dev), never in the product library
@@ -268,9 +282,9 @@ void launch_attn_full_probe(const float* qkv, float* out, const int* seq_off, co
                             int batch, int max_len, int variant, hipStream_t s) {
   const int nqb = (max_len + QB - 1) / QB;
   const dim3 grid(nqb * N_HEAD * batch), block(256);
-  if (variant == 1) hipLaunchKernelGGL((attn_full_kernel<1, 2>), grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, (const int*)nullptr, (const int*)nullptr);
-  else if (variant == 2) hipLaunchKernelGGL((attn_full_kernel<2, 2>), grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, (const int*)nullptr, (const int*)nullptr);
-  else hipLaunchKernelGGL((attn_full_kernel<3, 2>), grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, (const int*)nullptr, (const int*)nullptr);
+  if (variant == 1) hipLaunchKernelGGL((attn_full_kernel<1, 2>), grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, (const int*)nullptr, (const int*)nullptr, 1);
+  else if (variant == 2) hipLaunchKernelGGL((attn_full_kernel<2, 2>), grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, (const int*)nullptr, (const int*)nullptr, 1);
+  else hipLaunchKernelGGL((attn_full_kernel<3, 2>), grid, block, 0, s, qkv, out, seq_off, seq_len, prefix_len, nqb, (const int*)nullptr, (const int*)nullptr, 1);
 }
 
 #endif
