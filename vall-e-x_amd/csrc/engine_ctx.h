@@ -12,6 +12,7 @@
 #include <array>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/vallex_hip.h"
