@@ -393,8 +393,19 @@ void launch_gemm_f32(const GemmArgs& g_in, hipStream_t s, int variant) {
   // random operands): against the register-staged kernel the 256 x 256 DMA tile is -7.5 / -6.6 / -6.5 / -7.7 % at M = 31 616 (the
   // 256 x 128 one -4.4 / -4.8 / -2.1 / -2.6 %) and +13 % at M = 12 288 (48 x 12 tiles = 2.25 rounds on 256 CUs), where the 128 x 128 DMA
   // tile (two workgroups per CU) is -1.3 %; all four kernels agree bit for bit
-  if (variant == 0)
+  if (variant == 0) {
     variant = !(dma_ok && g.N % BN == 0 && g.M >= 2048) ? 1 : (g.M < 16384 ? 3 : (g.N % 256 == 0 ? 4 : 2));
+    static const bool tile_model = [] { const char* e = getenv("VX_GEMM_F32_TILES"); return !(e && e[0] == '0'); }();   // =0: A/B
+    if (variant == 4 && tile_model) {
+      // round 6: rounds of tiles on the 256 CUs.  The trimmed last layers of the NAR stages (19 200 rows x N = 1024: 300 tiles of
+      // 256 x 256 = 1.17 rounds, paid as 2) run 3 rounds of 256 x 128 tiles instead (a round of those is ~0.52 of a 256 x 256 round,
+      // profiles/r05_gemm_f32_ab.log); the full-length shapes keep 256 x 256 (6 vs 6.2, 2 vs 2.07, 8 vs 8.3 rounds)
+      const long rm = (g.M + 255) / 256;
+      const double c256 = (double)((rm * (g.N / 256) + 255) / 256);
+      const double c128 = (double)((rm * (g.N / 128) + 255) / 256) * 0.5175;
+      if (c128 < c256) variant = 2;
+    }
+  }
   if (variant != 1 && !dma_ok) variant = 1;
   if (variant == 2) {
     const int tiles = ((g.M + 255) / 256) * ((g.N + BN - 1) / BN);
