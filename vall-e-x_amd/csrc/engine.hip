@@ -357,6 +357,16 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
   const long o_rb = mb.add(row_b);
   const long o_sp = mb.add(st_pos), o_sc = mb.add(st_ctx), o_z = mb.add(st_zero), o_1 = mb.add(st_one), o_sS = mb.add(st_S),
              o_meta = mb.add(st_meta), o_slot = mb.add(st_slot);
+  // Row trimming of the LAST prefill layer (round 6; struct Trim): the decode only continues from the last row of every sequence
+  // (models/vallex.py:568: the logits of the newest position), so behind the K / V projection -- the cache needs every row -- the last
+  // layer runs its attention queries, out_proj and FFN on nb rows instead of M.
+  std::vector<int> tq_first(nb), tc_off(nb), t_rows(nb);
+  double trim_flops = 0;
+  for (int i = 0; i < nb; ++i) {
+    tq_first[i] = seq_len[i] - 1; tc_off[i] = i; t_rows[i] = seq_off[i] + seq_len[i] - 1;
+    trim_flops += 4.0 * seq_len[i] * D_MODEL;
+  }
+  const long o_tq = mb.add(tq_first), o_tc = mb.add(tc_off), o_tr = mb.add(t_rows);
   if (int e = upload_meta(c)) return e;
   const size_t ib = nrows * sizeof(int);
   HIPCHK(hipMemcpyAsync(c->cur_pos, mb.dev(o_sp), ib, hipMemcpyDeviceToDevice, c->stream));
@@ -408,9 +418,13 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
   double attn_flops = 0;
   for (int i = 0; i < nb; ++i) attn_flops += 4.0 * seq_len[i] * (double)seq_len[i] * D_MODEL;
   const size_t cache_layer = (size_t)c->mbr * N_HEAD * c->Tmax * D_HEAD;
+  const bool trim_h2 = c->gemm_mode == 0 && c->attn_x3 && c->attn_h2, trim_f32 = c->gemm_mode == 2 && !c->attn_x3;
+  const bool trim = c->nar_trim && (trim_h2 || trim_f32) && !c->cfg.debug_taps;      // the same switch as the NAR stages (VX_NAR_TRIM)
+  const Trim tr{nb, mb.dev(o_tq), mb.dev(o_tc), mb.dev(o_tr), trim_flops};
   for (int l = 0; l < NL; ++l) {
     if (int e = full_layer(c, c->ar[l], M, mb.dev(o_off), mb.dev(o_len), mb.dev(o_S), nb, max_len, nullptr, nullptr,
-                           c->kc + l * cache_layer, c->vc + l * cache_layer, mb.dev(o_rb), mb.dev(o_rt), attn_flops))
+                           c->kc + l * cache_layer, c->vc + l * cache_layer, mb.dev(o_rb), mb.dev(o_rt), attn_flops,
+                           (trim && l == NL - 1) ? &tr : nullptr))
       return e;
     if (c->cfg.debug_taps) {
       char nm[64];
@@ -418,10 +432,14 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
       if (int e = tap_store(c, nm, c->fx, (size_t)M * D_MODEL)) return e;
     }
   }
-  // last row of every sequence -> decode residual stream h[b]
-  for (int i = 0; i < nb; ++i)
-    HIPCHK(hipMemcpyAsync(c->dh + (size_t)i * D_MODEL, c->fx + ((size_t)seq_off[i] + seq_len[i] - 1) * D_MODEL,
-                          D_MODEL * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  // last row of every sequence -> decode residual stream h[b]  (trimmed: the last layer left exactly those rows, compacted, in the
+  // buffer full_layer uses for the compacted residual stream: fxn in f16x2 mode, the QKV buffer in fp32 mode)
+  if (trim)
+    HIPCHK(hipMemcpyAsync(c->dh, trim_h2 ? c->fxn : c->fqkv, (size_t)nb * D_MODEL * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  else
+    for (int i = 0; i < nb; ++i)
+      HIPCHK(hipMemcpyAsync(c->dh + (size_t)i * D_MODEL, c->fx + ((size_t)seq_off[i] + seq_len[i] - 1) * D_MODEL,
+                            D_MODEL * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
   // final norm + ar_predict_layer on those rows (models/vallex.py:568)
   launch_dec_reduce_ln_pack(nullptr, 0, D_MODEL, nullptr, c->dh, nullptr, W(c, "ar_decoder.norm.weight"),
                             W(c, "ar_decoder.norm.bias"), c->xp, nb, c->stream);
