@@ -79,7 +79,15 @@ def main():
                 d = np.argwhere(outs[i][:n] != ref[:n])
                 step = int(d[0][0]) if len(d) else n
                 cb = int(d[0][1]) if len(d) else -1
-                mg = first_step_margin(orc, r, u, top_k, temperature, step) if cb <= 0 else float("nan")
+                if cb <= 0:
+                    mg = first_step_margin(orc, r, u, top_k, temperature, step)
+                else:      # a NAR codebook: the oracle's own gap between the two largest logits of that stage at that frame (argmax decision)
+                    taps = {}
+                    orc.inference(r["text"][None], np.array([len(r["text"])]), r["prompt"][None], r["enroll"], top_k=top_k,
+                                  temperature=temperature, prompt_language=r["prompt_language"], text_language=r["text_language"],
+                                  uniforms=u, force_eos_at=cap, taps=taps)
+                    t2 = torch.topk(taps["nar_logits"][cb - 1][step].reshape(-1).double(), 2).values
+                    mg = float(t2[0] - t2[1])
                 diffs.append((i, outs[i].shape[0], ref.shape[0], step, cb, mg))
         rows_done += batch
         by_chain["<=4" if batch <= 4 else ("32" if batch == 32 else "5..31")] += 1

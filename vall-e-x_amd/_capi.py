@@ -287,10 +287,12 @@ class Engine:
         buf = np.zeros((n, stride, 8), np.int64)
         for i, c in enumerate(codes):
             buf[i, : c.shape[0]] = c
-        audio = np.zeros((n, stride * 320), np.float32)
+        # no zero fill and no second copy of the 24.6 MB a 32 x 8 s batch brings back: the library writes samples [0, 320 T_i) of row i
+        # and the rows are returned as views of this one fresh array (which they keep alive)
+        audio = np.empty((n, stride * 320), np.float32)
         self._chk(self.lib.vx_vocos_decode(self.ctx, _ptr(buf, C.c_int64), stride, _ptr(lens, C.c_int32), n,
                                            int(bandwidth_id), _ptr(audio, C.c_float), stride * 320))
-        return [audio[i, : lens[i] * 320].copy() for i in range(n)]
+        return [audio[i, : lens[i] * 320] for i in range(n)]
 
     def encodec_decode(self, codes: Sequence[np.ndarray]):
         n = len(codes)

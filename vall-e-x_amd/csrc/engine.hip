@@ -74,9 +74,16 @@ int xfer_sync(vx_ctx* c) {
       constexpr int NT = 4;
       std::thread th[NT - 1];
       auto work = [&pieces](int k) { for (size_t i = k; i < pieces.size(); i += NT) memcpy(pieces[i].dst, pieces[i].src, pieces[i].n); };
-      for (int k = 1; k < NT; ++k) th[k - 1] = std::thread(work, k);
+      bool started[NT - 1] = {};
+      for (int k = 1; k < NT; ++k) {
+        try { th[k - 1] = std::thread(work, k); started[k - 1] = true; }
+        catch (...) {}                                  // no thread to be had: this share is copied here, below (nothing crosses the C ABI)
+      }
       work(0);
-      for (auto& t : th) t.join();
+      for (int k = 1; k < NT; ++k) {
+        if (started[k - 1]) th[k - 1].join();
+        else work(k);
+      }
     }
   }
   r.pend.clear();
@@ -732,6 +739,14 @@ int nar_generate_once(vx_ctx* c, const vx_batch* b, int r0, int nb, const std::v
   long M = 0, Y = 0, sumT = 0;
   int max_len = 0;
   double trim_attn_flops = 0;
+  {      // the host builds ~0.3 M ints of row metadata while the GPU waits between the AR and the NAR phase: no reallocation on the way
+    size_t nS = 0, nY = 0, nT = 0;
+    for (int i = 0; i < nb; ++i) { nS += b->text_lens[r0 + i]; nY += b->prompt_lens[r0 + i] + T[i]; nT += T[i]; }
+    for (auto* v : {&dst_t, &id_t, &lang_t, &pos_t}) v->reserve(nS);
+    for (auto* v : {&ynj, &ydst, &ypos}) v->reserve(nY);
+    ycodes.reserve(nY * N_Q);
+    gen_rows.reserve(nT); gen_y.reserve(nT);
+  }
   for (int i = 0; i < nb; ++i) {
     const int r = r0 + i, S = b->text_lens[r], Tp = b->prompt_lens[r];
     seq_off[i] = (int)M; seq_len[i] = S + Tp + T[i];
