@@ -15,26 +15,7 @@ import torch  # noqa: E402
 from oracle import synth  # noqa: E402
 from oracle.vallex_oracle import VallexOracle  # noqa: E402
 from tests._util import get_model  # noqa: E402
-from tools.fuzz_soak import EOS_GAIN, NL, SEED  # noqa: E402
-
-
-def trial_rows(trial):
-    rng = np.random.default_rng(9000 + trial)
-    batch = int(rng.choice([1, 2, 3, 4, int(rng.integers(5, 32)), int(rng.integers(5, 32)), 32]))
-    mode = int(rng.integers(0, 4))
-    top_k, temperature = ((10, 1.0), (1, 1.0), (-100, 1.0), (10, 0.8))[mode]
-    cap = int(rng.integers(8, 49))
-    rows, cols = [], []
-    for i in range(batch):
-        tp = int(rng.choice([0, 1, 2, int(rng.integers(3, 201))]))
-        sp = 0 if tp == 0 else int(rng.integers(1, 41))
-        nt = int(rng.integers(1, 41))
-        a, t = synth.synth_prompt(tp, sp, seed=int(rng.integers(1, 1 << 30)))
-        txt = np.concatenate([t[0], synth.synth_text(nt, int(rng.integers(1, 1 << 30)))])
-        rows.append(dict(text=txt, prompt=a[0], enroll=sp, prompt_language=("en", "zh", "ja")[int(rng.integers(0, 3))],
-                         text_language=("en", "zh", "ja")[int(rng.integers(0, 3))]))
-        cols.append(synth.uniforms(4096, 1, int(rng.integers(1, 1 << 30)))[:, 0])
-    return rows, cols, top_k, temperature, cap
+from tools.fuzz_soak import EOS_GAIN, NL, SEED, trial_rows  # noqa: E402
 
 
 def main():

@@ -41,6 +41,26 @@ def first_step_margin(orc, r, u, top_k, temperature, step):
     return float(torch.min(torch.abs(cdf / cdf[-1] - float(u[step]))))
 
 
+def trial_rows(trial):
+    """the seeded random ragged batch of one trial: (rows, uniform columns, top_k, temperature, cap) -- shared with tools/fuzz_repro.py"""
+    rng = np.random.default_rng(9000 + trial)
+    batch = int(rng.choice([1, 2, 3, 4, int(rng.integers(5, 32)), int(rng.integers(5, 32)), 32]))
+    mode = int(rng.integers(0, 4))
+    top_k, temperature = ((10, 1.0), (1, 1.0), (-100, 1.0), (10, 0.8))[mode]
+    cap = int(rng.integers(8, 49))
+    rows, cols = [], []
+    for i in range(batch):
+        tp = int(rng.choice([0, 1, 2, int(rng.integers(3, 201))]))
+        sp = 0 if tp == 0 else int(rng.integers(1, 41))
+        nt = int(rng.integers(1, 41))
+        a, t = synth.synth_prompt(tp, sp, seed=int(rng.integers(1, 1 << 30)))
+        txt = np.concatenate([t[0], synth.synth_text(nt, int(rng.integers(1, 1 << 30)))])
+        rows.append(dict(text=txt, prompt=a[0], enroll=sp, prompt_language=("en", "zh", "ja")[int(rng.integers(0, 3))],
+                         text_language=("en", "zh", "ja")[int(rng.integers(0, 3))]))
+        cols.append(synth.uniforms(4096, 1, int(rng.integers(1, 1 << 30)))[:, 0])
+    return rows, cols, top_k, temperature, cap
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=540.0)
@@ -51,21 +71,8 @@ def main():
     t0 = time.time()
     trial, rows_done, bad, by_chain = args.first_trial, 0, 0, {"<=4": 0, "5..31": 0, "32": 0}
     while time.time() - t0 < args.seconds:
-        rng = np.random.default_rng(9000 + trial)
-        batch = int(rng.choice([1, 2, 3, 4, int(rng.integers(5, 32)), int(rng.integers(5, 32)), 32]))
-        mode = int(rng.integers(0, 4))
-        top_k, temperature = ((10, 1.0), (1, 1.0), (-100, 1.0), (10, 0.8))[mode]
-        cap = int(rng.integers(8, 49))
-        rows, cols = [], []
-        for i in range(batch):
-            tp = int(rng.choice([0, 1, 2, int(rng.integers(3, 201))]))
-            sp = 0 if tp == 0 else int(rng.integers(1, 41))
-            nt = int(rng.integers(1, 41))
-            a, t = synth.synth_prompt(tp, sp, seed=int(rng.integers(1, 1 << 30)))
-            txt = np.concatenate([t[0], synth.synth_text(nt, int(rng.integers(1, 1 << 30)))])
-            rows.append(dict(text=txt, prompt=a[0], enroll=sp, prompt_language=("en", "zh", "ja")[int(rng.integers(0, 3))],
-                             text_language=("en", "zh", "ja")[int(rng.integers(0, 3))]))
-            cols.append(synth.uniforms(4096, 1, int(rng.integers(1, 1 << 30)))[:, 0])
+        rows, cols, top_k, temperature, cap = trial_rows(trial)
+        batch = len(rows)
         outs = m.inference_batch(rows, top_k=top_k, temperature=temperature, uniforms=np.stack(cols, axis=1), force_eos_at=cap)
         fb = m.engine.last_fallbacks()
         lens, diffs = [], []
