@@ -80,3 +80,14 @@ def test_loopback_world_reassembles_a_job_like_ranks_would():
         got = gather_rows(a, mine, 37, bench.LoopbackWorld(parts))
         assert bench.ids_digest(got) == bench.ids_digest(job)
     assert bench.ids_digest(job[:5]) != bench.ids_digest(job[1:6]) and len(bench.ids_digest(job)) == 16
+
+
+def test_newest_pmc_files_were_measured_on_the_kernel_sources_in_this_tree():
+    """bench.py quotes `roofline.traffic` from the newest profiles/rNN_pmc_<kernel>.json and refuses a file whose source digest is not
+    the digest of the kernel's translation unit (+ vx_common.h) in this tree.  For the kernel classes the default line and its fp32 leg
+    report, the committed files must be fresh -- otherwise the driver's BENCH line would carry `traffic: null`."""
+    import bench
+    for k in ("dec_attn", "gemm_f16x2", "attn_full_h2", "skinny_gemm", "skinny16", "gemm_f32", "attn_full"):
+        pj, src, stale = bench.newest_pmc(k)
+        assert pj is not None and not stale, (k, src, "re-run tools/gpu_call.sh evidence NN [f32] after changing a kernel source")
+        assert pj["traffic_bytes_per_launch"] > 0 and pj.get("by_symbol"), (k, src)
