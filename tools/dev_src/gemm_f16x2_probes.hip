@@ -358,7 +358,7 @@ __global__ __launch_bounds__(512, V == 13 ? 2 : 1) void gemm_f16x2_probe_kernel(
 // requests of tile kt + 2 are issued -- one behind every third MFMA -- during the second step of tile kt, so that they have a whole
 // k16 step (>= 1 536 matrix-pipe cycles) left to land before the rendezvous of tile kt + 1 asks for them.  Inline-asm LDS reads
 // with counted waits (a C++ LDS load behind an LDS-DMA makes the compiler wait for the DMA).
-__global__ __launch_bounds__(256, 1) void gemm_f16x2_w128_kernel(GemmX3Args g) {
+__global__ __launch_bounds__(256, 1) void gemm_f16x2_w128_probe_kernel(GemmX3Args g) {
   constexpr int TN = 256, HW_PL = TN * HLD, HSTAGE = 2 * HA_PL + 2 * HW_PL;     // 64 KiB per stage
   __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * HSTAGE];
   constexpr int GM = 8;
@@ -538,7 +538,7 @@ void launch_gemm_f16x2_probe(const GemmX3Args& g, int variant, hipStream_t s) {
   }
   else if (variant == 23) {                                        // round 5: 128 x 128 per-wave tiles, 4 waves, full software pipeline
     if (g.N % 256 != 0 || g.K % 64 != 0) return;
-    hipLaunchKernelGGL(gemm_f16x2_w128_kernel, dim3(((g.M + HM - 1) / HM) * (g.N / 256)), dim3(256), 0, s, g);
+    hipLaunchKernelGGL(gemm_f16x2_w128_probe_kernel, dim3(((g.M + HM - 1) / HM) * (g.N / 256)), dim3(256), 0, s, g);
   }
   else if (variant >= 16 && variant <= 22) {    // 19: the 256 x 256 kernel with the DMA instructions back to back (before round 3)    // 16: see the kernel; 17 / 18: probes 1 / 2 (no DMA / no MFMAs) on the 256 x 256 tile
     const dim3 grid256(((g.M + HM - 1) / HM) * (g.N / 256));

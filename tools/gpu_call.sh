@@ -14,7 +14,7 @@
 #   bench LABEL [bench.py args]    one bench.py line -> <tag>_bench_LABEL.json (+ .err)
 #   cbench LABEL [ENV=V ...] -- [c_bench args]      one run of the torch-free C client (examples/c_bench.c) -> <tag>_cbench.jsonl
 #   env_ab VAR ROUNDS [c_bench args]                the C client with VAR=0 / VAR=1 alternating (ONE library, a runtime switch)
-#   lib_ab "base v1 v2" ROUNDS [c_bench args]       the C client on complete library variants (tools/devx_<name>/, _build.py --variant)
+#   lib_ab base,v1,v2 ROUNDS [c_bench args]         the C client on complete library variants (tools/devx_<name>/, _build.py --variant)
 #   gemm_operands                  is gemm_f16x2 power- or schedule-bound: the same launch on random / zero-tail / zero / constant operands
 #   gemm_f32_ab [ROUNDS]           the fp32-MFMA GEMM kernels (register-staged / LDS-DMA 256 x 128 / LDS-DMA 128 x 128) on the four NAR shapes
 #   walk [REPS]                    tile-order sweep of gemm_f16x2_w128 / gemm_f32_dma<256,256> (tools/gemm_walk_sweep.py): us per shape and walk,
@@ -100,7 +100,7 @@ step_env_ab() {
 }
 step_lib_ab() {
   need_cbench || return 1
-  local variants="$1" rounds="$2"; shift 2
+  local variants="${1//,/ }" rounds="$2"; shift 2      # comma-separated (a step's arguments are split on blanks): base,v1,v2
   [ $# -eq 0 ] && set -- --steps 3 --warmup 1
   printf "%-22s %8s %8s %8s %8s  %s\n" variant ms_step ar_ms nar_ms audio_s digest | tee -a gpurun_out/${TAG}_cbench.txt
   for r in $(seq 1 "$rounds"); do
