@@ -104,3 +104,25 @@ def test_checkpoint_verifier_on_the_gpu(tmp_path):
     assert all(v["equal"] for v in rep["parity"]["cross_arith"].values()) and len(rep["parity"]["cross_arith"]) == 4
     assert all(j["fallbacks"]["lifetime"] == 0 for j in rep["parity"]["f16x2"].values())
     assert rep["vocos"]["rms_vs_cpu_restatement"] <= 1e-4 and "pip_vocos" in rep["vocos"]
+
+
+def test_dev_build_has_no_duplicate_kernel_symbols():
+    """the tools-only dev library (vall-e-x_amd/_build.py --dev) links the product translation units PLUS tools/dev_src/*.hip into one
+    shared object: a kernel promoted from the probe file to the product must be renamed in the probe file, or the dev link fails with a
+    duplicate symbol (it did, silently, for a round).  Static check of the non-template __global__ names (templates may repeat)."""
+    import re
+    pat = re.compile(r"^(template\s*<[^>]*>\s*)?__global__[^;{]*?\bvoid\s+(\w+)\s*\(", re.M | re.S)
+
+    def kernels(path):
+        return {m.group(2) for m in pat.finditer(open(path).read()) if not m.group(1)}
+    product = {}
+    for f in glob.glob(os.path.join(ROOT, "vall-e-x_amd", "csrc", "*.hip")):
+        if os.path.basename(f) == "preflight.hip":      # its own executable
+            continue
+        for k in kernels(f):
+            assert k not in product, (k, f, product[k])
+            product[k] = f
+    assert len(product) > 30
+    for f in glob.glob(os.path.join(ROOT, "tools", "dev_src", "*.hip")):
+        dup = kernels(f) & set(product)
+        assert not dup, (os.path.basename(f), sorted(dup))
