@@ -75,9 +75,30 @@ void dev_clear_stamps() {
 #define VX_STAMP(TYPE, SLOT)
 #endif
 
+// Results of the kernels of the 5 .. 32-row decode chain are stored WRITE-THROUGH at agent scope (`sc1`).  The step is a chain of
+// dependent launches and a kernel ends with the release of its writes -- the write-back of whatever its XCD's L2 still holds dirty
+// (the 8 L2s are not coherent with each other); a result that went through to memory when it was stored leaves nothing to write
+// back.  tools/ubench/boundary_cost.hip: 0.2-0.3 us less per link of a graph chain (profiles/r06_boundary_cost.txt); the 32-row
+// step: AR 454.7 -> 446.9 ms per batch, same ids digest (profiles/r06_wt_stores_ab.log).  Same values, bit-identical.  NOT for the
+// <= 4-row chain: its consumers rebuild their input rows in EVERY workgroup and find a plainly stored result in the L2 of the XCD
+// that wrote it (1 row: AR +5.3 ms, 4 rows: +9.7 ms with write-through, same log), and not for the rows a step appends to the K / V
+// cache or the sampler's row state (+5 ms at 32 rows).  The consumer of a result is always a LATER launch, so the asm needs no
+// ordering against this kernel's own loads.  -DVX_DEC_WT=0: plain stores everywhere (A/B builds).
+#ifndef VX_DEC_WT
+#define VX_DEC_WT 1
+#endif
+__device__ __forceinline__ void store_result(float* p, const f32x4& v, bool wt = true) {
+  if (VX_DEC_WT != 0 && wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+  else *reinterpret_cast<f32x4*>(p) = v;
+}
+__device__ __forceinline__ void store_result(float* p, float v, bool wt = true) {
+  if (VX_DEC_WT != 0 && wt) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+  else *p = v;
+}
+
 // output: raw split-K partial slab [ks][b][n] (row-major per batch row; consumers: dec_attn, dec_reduce_ln_pack, dec_sample)
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restrict__ Wp, const float* __restrict__ xp,
-                                                          float* __restrict__ out, int Npad, int K, int splitk) {
+                                                          float* __restrict__ out, int Npad, int K, int splitk, int wt) {
   __shared__ __attribute__((aligned(16))) float red[4 * 16 * 64];
   const int stype_ = Npad == 3 * D_MODEL ? 0 : (Npad == D_MODEL ? 1 : 2);
   (void)stype_;
@@ -135,13 +156,14 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const float* __restric
     t[j] = ((rp[0] + rp[16 * 64]) + rp[2 * 16 * 64]) + rp[3 * 16 * 64];
   }
   float* dst = out + ((long)ks * MB + (lane & 31)) * Npad + nt * 32 + 4 * (lane >> 5);
-  *reinterpret_cast<f32x4*>(dst + wid * 8) = t;
+  store_result(dst + wid * 8, t, wt != 0);
   VX_STAMP(stype_, 4);
 }
 
+// wt: write-through result stores (store_result above) -- the 5 .. 32-row decode chain only
 void launch_skinny_gemm(const float* Wp, const float* xp, float* partial, int Npad, int K, int splitk,
-                        hipStream_t s) {
-  hipLaunchKernelGGL(skinny_gemm_kernel, dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, xp, partial, Npad, K, splitk);
+                        hipStream_t s, bool wt) {
+  hipLaunchKernelGGL(skinny_gemm_kernel, dim3(Npad / 32, splitk), dim3(256), 0, s, Wp, xp, partial, Npad, K, splitk, wt ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -203,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void skinny_qkv_bal_kernel(const float* __r
     t[j] = ((rp[0] + rp[16 * 64]) + rp[2 * 16 * 64]) + rp[3 * 16 * 64];
   }
   float* dst = out + ((long)ks * MB + (lane & 31)) * Npad + nt * 32 + 4 * (lane >> 5);
-  *reinterpret_cast<f32x4*>(dst + wid * 8) = t;
+  store_result(dst + wid * 8, t);
 }
 
 void launch_skinny_qkv_balanced(const float* Wp, const float* xp, float* partial, hipStream_t s) {
@@ -297,7 +319,7 @@ __global__ __launch_bounds__(S16_WAVES * 64) void skinny16_relu_pack_kernel(cons
     for (int r = 0; r < 4; ++r) a4[r] = fmaxf(a4[r] + bi[r], 0.f);
     // n = 16nt + 4kg + r  ->  linear2's k: kb = 2nt + (kg>>1), hi = kg&1, j = r
     float* o = xp_out + (((long)(2 * nt + (kg >> 1)) * 64) + bl + 32 * (kg & 1)) * 4;
-    *reinterpret_cast<f32x4*>(o + wid * 16 * 4) = a4;
+    store_result(o + wid * 16 * 4, a4);
   }
   VX_STAMP(3, 4);
 }
@@ -333,7 +355,7 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // One 64-lane wave per batch row: lane l owns float4 columns c4 = l + 64 i (i < 4) of the 1024 -- no LDS, no barriers.
 // LayerNorm (two-pass, registers) written in the packed-x image: float4 column c4 -> kb = c4>>1, hi = c4&1.
 __device__ __forceinline__ void ln_pack_row(const f32x4 (&v)[4], int b, const f32x4 (&gg)[4], const f32x4 (&be)[4],
-                                            float* __restrict__ xp) {
+                                            float* __restrict__ xp, bool wt = false) {
   const int lane = threadIdx.x;
   float s = 0.f;
 #pragma unroll
@@ -351,7 +373,7 @@ __device__ __forceinline__ void ln_pack_row(const f32x4 (&v)[4], int b, const f3
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gg[i][e] + be[i][e];
-    *reinterpret_cast<f32x4*>(xp + (((long)(c4 >> 1) * 64) + b + 32 * (c4 & 1)) * 4) = o;
+    store_result(xp + (((long)(c4 >> 1) * 64) + b + 32 * (c4 & 1)) * 4, o, wt);
   }
 }
 
@@ -388,7 +410,7 @@ __global__ __launch_bounds__(256) void dec_reduce_ln_pack_kernel(const float* __
   if (resid)
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = r[e] + v[e];
-  if (h) *reinterpret_cast<f32x4*>(h + (long)b * D_MODEL + c) = v;
+  if (h) store_result(h + (long)b * D_MODEL + c, v);
   VX_STAMP(SK == 16 ? 4 : 5, 2);
   // LayerNorm (F.layer_norm, eps 1e-5): mean, then the centred second moment
   float s1 = wave_sum64((v[0] + v[1]) + (v[2] + v[3]));
@@ -406,7 +428,7 @@ __global__ __launch_bounds__(256) void dec_reduce_ln_pack_kernel(const float* __
 #pragma unroll
   for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * gg[e] + be[e];
   // packed-x image: float4 column c4 = t -> kb = c4 >> 1, hi = c4 & 1
-  *reinterpret_cast<f32x4*>(xp + (((long)(t >> 1) * 64) + b + 32 * (t & 1)) * 4) = o;
+  store_result(xp + (((long)(t >> 1) * 64) + b + 32 * (t & 1)) * 4, o);
   VX_STAMP(SK == 16 ? 4 : 5, 4);
 }
 
@@ -1002,11 +1024,11 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
       for (int e = 0; e < 4; ++e) ot[e] *= inv;
       if (FUSE_OUT) *reinterpret_cast<f32x4*>(&sh_ot[r][c * 4]) = ot;
       // column k = h*64 + 4c: kb = h*8 + (c>>1), hi = c&1
-      else *reinterpret_cast<f32x4*>(xp_out + (((long)(h * 8 + (c >> 1)) * 64) + b + 32 * (c & 1)) * 4) = ot;
+      else store_result(xp_out + (((long)(h * 8 + (c >> 1)) * 64) + b + 32 * (c & 1)) * 4, ot);
     } else {
       const long pi = ((long)(b * N_HEAD + h) * nsplit + sp);
-      *reinterpret_cast<f32x4*>(part_o + pi * D_HEAD + c * 4) = ot;
-      if (c == 0) { part_ml[pi * 2] = mt; part_ml[pi * 2 + 1] = lt; }
+      store_result(part_o + pi * D_HEAD + c * 4, ot);
+      if (c == 0) { store_result(part_ml + pi * 2, mt); store_result(part_ml + pi * 2 + 1, lt); }
     }
   }
   VX_STAMP(6, 3);
@@ -1037,7 +1059,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
     for (int rr = 0; rr < NR; ++rr) {
       if (!live_rr[rr]) continue;
       const int br = slot_meta[4 * ((int)blockIdx.y + rr * gy)];
-      out_heads[((long)h * MB + br) * D_MODEL + threadIdx.x] = acc[rr];
+      store_result(out_heads + ((long)h * MB + br) * D_MODEL + threadIdx.x, acc[rr]);
     }
   }
   VX_STAMP(6, 4);
@@ -1621,9 +1643,9 @@ __global__ __launch_bounds__(64) void dec_sample_kernel(SampleArgs a) {
     hv[i] = *reinterpret_cast<const f32x4*>(a.emb_tab + (long)tok * D_MODEL + cc);
 #pragma unroll
     for (int q = 0; q < 4; ++q) hv[i][q] = __fadd_rn(hv[i][q], __fmul_rn(alpha, pe4[i][q]));
-    *reinterpret_cast<f32x4*>(a.emb_h + (long)b * D_MODEL + cc) = hv[i];
+    store_result(a.emb_h + (long)b * D_MODEL + cc, hv[i], a.wt != 0);
   }
-  ln_pack_row(hv, b, gg, be, a.emb_xp);
+  ln_pack_row(hv, b, gg, be, a.emb_xp, a.wt != 0);
   VX_STAMP(7, 4);
 }
 

@@ -482,6 +482,7 @@ SampleArgs make_sample_args(vx_ctx* c, const vx_sampling* s, int commit, float* 
   if (commit) {      // the sampler also embeds the committed token and applies norm1 of layer 0 (start of the next step)
     a.emb_tab = W(c, "ar_audio_embedding.word_embeddings.weight"); a.emb_alpha = W(c, "ar_audio_position.alpha");
     a.pe = c->pe; a.ln_g = c->ar[0].n1_w; a.ln_b = c->ar[0].n1_b; a.emb_h = c->dh; a.emb_xp = c->xp;
+    a.wt = c->sb_chain ? 0 : 1;
   }
   return a;
 }
@@ -553,7 +554,7 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
     {
       ProfScope ps(c, 1);
       if (c->qkv_bal) launch_skinny_qkv_balanced(L.in_wp, c->xp, c->p_qkv, st);
-      else launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, st);
+      else launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, st, true);
     }
     const bool fused = c->fuse_out && c->nsplit == 1;
     {
@@ -565,16 +566,16 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
       launch_dec_reduce_ln_pack(c->p_oh, N_HEAD, D_MODEL, L.out_b, c->dh, c->dh, L.n2_w, L.n2_b, c->xp, nb, st);
     } else {
       if (c->nsplit > 1) launch_dec_attn_combine(c->part_o, c->part_ml, c->nsplit, c->active, c->xp_att, nb, st);
-      { ProfScope ps(c, 1); launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, st); }
+      { ProfScope ps(c, 1); launch_skinny_gemm(L.out_wp, c->xp_att, c->p_o, D_MODEL, D_MODEL, SK_OUT, st, true); }
       launch_dec_reduce_ln_pack(c->p_o, SK_OUT, D_MODEL, L.out_b, c->dh, c->dh, L.n2_w, L.n2_b, c->xp, nb, st);
     }
     { ProfScope ps(c, 1); launch_skinny16_relu_pack(L.l1_wp, c->xp, L.l1_b, c->xp4, D_FF, D_MODEL, st); }
-    { ProfScope ps(c, 1); launch_skinny_gemm(L.l2_wp, c->xp4, c->p_o, D_MODEL, D_FF, SK_L2, st); }
+    { ProfScope ps(c, 1); launch_skinny_gemm(L.l2_wp, c->xp4, c->p_o, D_MODEL, D_FF, SK_L2, st, true); }
     const float* ng = (l + 1 < NL) ? c->ar[l + 1].n1_w : W(c, "ar_decoder.norm.weight");
     const float* nbp = (l + 1 < NL) ? c->ar[l + 1].n1_b : W(c, "ar_decoder.norm.bias");
     launch_dec_reduce_ln_pack(c->p_o, SK_L2, D_MODEL, L.l2_b, c->dh, c->dh, ng, nbp, c->xp, nb, st);
   }
-  { ProfScope ps(c, 1); launch_skinny_gemm(c->pred_wp, c->xp, c->p_logits, PRED_NPAD, D_MODEL, SK_PRED, st); }
+  { ProfScope ps(c, 1); launch_skinny_gemm(c->pred_wp, c->xp, c->p_logits, PRED_NPAD, D_MODEL, SK_PRED, st, true); }
   if (sa) LAUNCH(launch_dec_sample(*sa, st));
 }
 

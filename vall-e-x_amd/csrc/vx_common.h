@@ -171,7 +171,7 @@ void launch_attn_full_probe(const float* qkv, float* out, const int* seq_off, co
 // packed skinny-GEMM weight image: tiles of 32 n-rows x 8 k, lane-linear (see decode.hip)
 void launch_pack_weight(const float* W, int N, int K, float* Wp, int Npad, hipStream_t s);
 // partial[ks][b][n] = sum_{k in slice ks} x[b][k] * W[n][k];  xp is the packed activation image.
-void launch_skinny_gemm(const float* Wp, const float* xp, float* partial, int Npad, int K, int splitk, hipStream_t s);
+void launch_skinny_gemm(const float* Wp, const float* xp, float* partial, int Npad, int K, int splitk, hipStream_t s, bool wt = false);
 // slab counts of the balanced in_proj (skinny_qkv_bal_kernel): q in 8 K slices, k / v in 4.  dec_attn_kernel's SK template parameter
 // carries both as SKQ * 10 + SKV (a plain count <= 10 means the same count for q, k and v: skinny_gemm_kernel with splitk = 4).
 constexpr int SK_QKV_BAL_Q = 8, SK_QKV_BAL_KV = 4;
@@ -240,6 +240,7 @@ struct SampleArgs {
   // optional fused start of the next step (dec_embed_ln_pack for the committed token); emb_tab == null: off
   const float* emb_tab; const float* emb_alpha; const float* pe; const float* ln_g; const float* ln_b;
   float* emb_h; float* emb_xp;
+  int wt;                                          // write-through stores of emb_h / emb_xp (decode.hip store_result: the 5 .. 32-row chain)
 };
 bool launch_dec_sample(const SampleArgs& a, hipStream_t s);
 #ifdef VX_DEV_PROBES
