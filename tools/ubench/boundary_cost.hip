@@ -31,13 +31,20 @@ __global__ __launch_bounds__(256) void w_kernel(float* __restrict__ out, float s
   else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
 }
 
+// LMODE: how the consumer loads (0 plain, 1 nt, 2 sc1, 3 sc0 sc1) -- second table of main()
+template <int LMODE = 0>
 __global__ __launch_bounds__(256) void r_kernel(const float* __restrict__ in, long n4, float* __restrict__ sink) {
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 257 % n4;      // a line some other workgroup (another XCD) wrote
-  const f32x4 v = reinterpret_cast<const f32x4*>(in)[i];
+  const f32x4* p = reinterpret_cast<const f32x4*>(in) + i;
+  f32x4 v;
+  if (LMODE == 0) v = *p;
+  else if (LMODE == 1) v = __builtin_nontemporal_load(p);
+  else if (LMODE == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
   if (threadIdx.x == 0) sink[blockIdx.x] = v[0] + v[3];
 }
 
-template <int MODE>
+template <int MODE, int LMODE = 0>
 double chain(float* buf, float* sink, int G, int links, int reps, int what /* 0 pairs, 1 W only, 2 R only */) {
   hipStream_t s;
   CHECK(hipStreamCreate(&s));
@@ -47,7 +54,7 @@ double chain(float* buf, float* sink, int G, int links, int reps, int what /* 0 
   CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   for (int l = 0; l < links; ++l) {
     if (what != 2) hipLaunchKernelGGL(w_kernel<MODE>, dim3(G), dim3(256), 0, s, buf, (float)l);
-    if (what != 1) hipLaunchKernelGGL(r_kernel, dim3(256), dim3(256), 0, s, buf, n4, sink);
+    if (what != 1) hipLaunchKernelGGL(r_kernel<LMODE>, dim3(256), dim3(256), 0, s, buf, n4, sink);
   }
   CHECK(hipStreamEndCapture(s, &g));
   CHECK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
@@ -89,5 +96,10 @@ int main(int argc, char** argv) {
            chain<2>(buf, sink, G, links, reps, 1), chain<3>(buf, sink, G, links, reps, 1));
   }
   printf("%-28s %10.2f\n", "R alone (1 MiB source)", chain<0>(buf, sink, 256, links, reps, 2));
+  printf("\nconsumer's load flavour (producer: sc1 stores, 1 MiB)\n%-28s %10s %10s %10s %10s\n", "", "plain", "nt", "sc1", "sc0 sc1");
+  printf("%-28s %10.2f %10.2f %10.2f %10.2f\n", "W(1024 KiB) -> R   pairs", chain<2, 0>(buf, sink, 256, links, reps, 0), chain<2, 1>(buf, sink, 256, links, reps, 0),
+         chain<2, 2>(buf, sink, 256, links, reps, 0), chain<2, 3>(buf, sink, 256, links, reps, 0));
+  printf("%-28s %10.2f %10.2f %10.2f %10.2f\n", "R alone", chain<0, 0>(buf, sink, 256, links, reps, 2), chain<0, 1>(buf, sink, 256, links, reps, 2),
+         chain<0, 2>(buf, sink, 256, links, reps, 2), chain<0, 3>(buf, sink, 256, links, reps, 2));
   return 0;
 }
