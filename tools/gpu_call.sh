@@ -56,7 +56,7 @@ step_golden() {
   env "$@" timeout 600 python -m pytest $GOLDEN -m gpu -q -x 2>&1 | tail -3 | tee -a gpurun_out/${TAG}_golden.log
 }
 step_switches() {
-  for sw in VX_SB_QKV=0 VX_SB_FUSE=0 VX_FUSE_OUT=0 VX_BALANCE_ROWS=0 VX_NAR_TRIM=0 VX_GEMM_X3=1 VX_ATTN_X3=1 VX_GEMM_F32=1 VX_ATTN_F32=1; do
+  for sw in VX_SB_QKV=0 VX_SB_FUSE=0 VX_FUSE_OUT=0 VX_FUSE_SPLIT=0 VX_BALANCE_ROWS=0 VX_NAR_TRIM=0 VX_GEMM_X3=1 VX_ATTN_X3=1 VX_GEMM_F32=1 VX_ATTN_F32=1; do
     step_golden $sw
   done
   gcc -std=c99 -Wall -Wextra -Werror -pedantic -Iinclude examples/c_client.c $LF -o /tmp/c_client && /tmp/c_client --run 2>&1 | tail -4 | tee -a gpurun_out/${TAG}_golden.log

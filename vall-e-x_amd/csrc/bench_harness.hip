@@ -86,7 +86,7 @@ int vx_bench_kernel(vx_ctx* c, int32_t which, int32_t reps, int32_t gen_offset, 
     const size_t cache_layer = (size_t)c->mbr * N_HEAD * c->Tmax * D_HEAD;
     auto attn_l = [&](int r) {
       const int l = r % c->NL;
-      const bool fused = c->fuse_out && c->nsplit == 1;
+      const bool fused = c->fuse_out && (c->nsplit == 1 || c->split_fused);
       // slab counts of the product's in_proj (84 = 8 slabs of q, 4 of k / v: skinny_qkv_bal_kernel)
       launch_dec_attn(c->p_qkv, c->qkv_bal ? 84 : SK_QKV, c->ar[l].in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax,
                       c->slot_meta, c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, fused ? c->ar[l].out_wh : nullptr, c->p_oh,

@@ -442,6 +442,87 @@ void launch_dec_reduce_ln_pack(const float* partial, int splitk, int npad, const
 #undef VX_RLP
 }
 
+// Consumer of the fused out_proj WITH context splits (dec_attn_kernel<true, *, true>): row b's attention output through out_proj is
+//   sum_h sum_s w(h, s) * slab[h * NS + s][b][:],  w(h, s) = e^(m_s - M_h) / sum_s' e^(m_s' - M_h) l_s'   (the combine of
+// dec_attn_combine_kernel applied BEHIND the head's W_o slice: out_proj is linear), summed in ascending (h, s) order; then bias,
+// residual, LayerNorm and pack exactly as dec_reduce_ln_pack_kernel.  One 256-thread block per row.
+template <int NS>
+__global__ __launch_bounds__(256) void dec_reduce_ln_split_kernel(const float* __restrict__ slabs, const float* __restrict__ part_ml,
+                                                                  const float* __restrict__ bias, const float* __restrict__ resid,
+                                                                  float* __restrict__ h, const float* __restrict__ g,
+                                                                  const float* __restrict__ bb, float* __restrict__ xp) {
+  __shared__ float red[2][4];
+  __shared__ float wsh[N_HEAD * NS];
+  const int b = blockIdx.x, t = threadIdx.x, wid = t >> 6, c = t * 4;
+  constexpr int HC = 4;                              // heads per chunk: HC * NS 16-byte loads in flight per thread
+  f32x4 p[HC * NS];
+  const float* sl = slabs + (long)b * D_MODEL + c;
+#pragma unroll
+  for (int i = 0; i < HC * NS; ++i) p[i] = *reinterpret_cast<const f32x4*>(sl + (long)i * MB * D_MODEL);
+  if (t < N_HEAD) {                                  // thread t: the weights of head t
+    const float* ml = part_ml + (long)(b * N_HEAD + t) * NS * 2;
+    float m[NS], l[NS], mt = -1e30f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { m[s] = ml[2 * s]; l[s] = ml[2 * s + 1]; mt = fmaxf(mt, m[s]); }
+    float a[NS], lt = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { a[s] = expf(m[s] - mt); lt += l[s] * a[s]; }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) wsh[t * NS + s] = a[s] / lt;
+  }
+  const f32x4 gg = *reinterpret_cast<const f32x4*>(g + c), be = *reinterpret_cast<const f32x4*>(bb + c);
+  const f32x4 r = *reinterpret_cast<const f32x4*>(resid + (long)b * D_MODEL + c);
+  const f32x4 bi = *reinterpret_cast<const f32x4*>(bias + c);
+  __syncthreads();
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int hc = 0; hc < N_HEAD / HC; ++hc) {
+    f32x4 q[HC * NS];
+    if (hc + 1 < N_HEAD / HC) {
+#pragma unroll
+      for (int i = 0; i < HC * NS; ++i) q[i] = *reinterpret_cast<const f32x4*>(sl + (long)((hc + 1) * HC * NS + i) * MB * D_MODEL);
+    }
+#pragma unroll
+    for (int i = 0; i < HC * NS; ++i) {
+      const float w = wsh[hc * HC * NS + i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaf(w, p[i][e], v[e]);
+    }
+#pragma unroll
+    for (int i = 0; i < HC * NS; ++i) p[i] = q[i];
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = r[e] + (v[e] + bi[e]);
+  store_result(h + (long)b * D_MODEL + c, v);
+  float s1 = wave_sum64((v[0] + v[1]) + (v[2] + v[3]));
+  if ((t & 63) == 0) red[0][wid] = s1;
+  __syncthreads();
+  const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * (1.0f / D_MODEL);
+  float q2 = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q2 += d * d; }
+  q2 = wave_sum64(q2);
+  if ((t & 63) == 0) red[1][wid] = q2;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * (1.0f / D_MODEL) + LN_EPS);
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * rstd * gg[e] + be[e];
+  store_result(xp + (((long)(t >> 1) * 64) + b + 32 * (t & 1)) * 4, o);
+}
+
+// false = this split count is not instantiated (nothing launched)
+bool launch_dec_reduce_ln_split(const float* slabs, const float* part_ml, int nsplit, const float* bias, const float* resid, float* h,
+                                const float* g, const float* b, float* xp, int batch, hipStream_t s) {
+#define VX_RLS(NSV) hipLaunchKernelGGL((dec_reduce_ln_split_kernel<NSV>), dim3(batch), dim3(256), 0, s, slabs, part_ml, bias, resid, h, g, b, xp)
+  if (nsplit == 2) VX_RLS(2);
+  else if (nsplit == 3) VX_RLS(3);
+  else if (nsplit == 4) VX_RLS(4);
+  else return false;
+#undef VX_RLS
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Small batches (<= SB_MAX rows; BASELINE config 2 is ONE utterance): the step is a pure chain of launch latencies, so the tiny
 // kernels between the weight-streaming GEMMs are folded into the GEMM that consumes their output.  EVERY workgroup of the
@@ -797,7 +878,11 @@ static_assert(ATT_STRIDE == DEC_ATTN_TILE, "the engine's Tmax guard for the fuse
 // The fused variant runs TWO rows of the same head per workgroup (16 waves: waves 0-7 stream launch slot y, waves 8-15 slot
 // y + ceil(batch/2) -- with the engine's row order a long and a short context), so the head's 256 KiB W_o slice, whose
 // L2 -> CU read (64 B/clk per CU) is what the epilogue costs, is read once per two rows.
-template <bool FUSE_OUT, int SK>
+// SPLIT (FUSE_OUT only, round 6: 5 .. 16 rows): the fused out_proj WITH context splits.  out_proj is linear, so the workgroup of split
+// sp multiplies its UNNORMALISED partial output (o_s = sum p v, p = exp(s - m_s)) with the head's W_o slice and writes slab h * nsplit + sp;
+// (m_s, l_s) go to part_ml as in the unfused kernel and dec_reduce_ln_split_kernel weighs the slabs: out = sum_h sum_s (e^(m_s - M_h) / L_h) W_o,h o_s.
+// Two launches per layer fewer than dec_attn | dec_attn_combine | out_proj GEMM.
+template <bool FUSE_OUT, int SK, bool SPLIT = false>
 __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_attn_kernel(
     // the first 16 dwords arrive preloaded in SGPRs (-amdgpu-kernarg-preload-count=16, _build.py): everything the requests at the
     // head of the kernel are built from -- the K / V arena, the slot records, Tmax, batch -- sits there; an argument behind them
@@ -836,7 +921,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
 #if defined(VX_DEC_ATTN_LATE_TILE)             // A/B builds: the first tile behind the record, as until round 4
   constexpr bool early = false;
 #else
-  constexpr bool early = FUSE_OUT;            // the engine only fuses when Tmax >= DEC_ATTN_TILE (weights.hip)
+  constexpr bool early = FUSE_OUT && !SPLIT;  // the engine only fuses when Tmax >= DEC_ATTN_TILE (weights.hip); a split's rows start at t0: behind the record
 #endif
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   i32x4 meta = *reinterpret_cast<const i32x4*>(slot_meta + 4 * (valid ? slot : 0));
@@ -1018,7 +1103,14 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
 #pragma unroll
       for (int e = 0; e < 4; ++e) ot[e] += ow[e] * a;
     }
-    if (nsplit == 1) {
+    if constexpr (FUSE_OUT && SPLIT) {
+      *reinterpret_cast<f32x4*>(&sh_ot[r][c * 4]) = ot;        // unnormalised: the consumer holds every split's (m, l)
+      if (c == 0 && valid) {
+        const long pi = ((long)(b * N_HEAD + h) * nsplit + sp);
+        store_result(part_ml + pi * 2, mt);
+        store_result(part_ml + pi * 2 + 1, lt);
+      }
+    } else if (nsplit == 1) {
       const float inv = 1.0f / lt;
 #pragma unroll
       for (int e = 0; e < 4; ++e) ot[e] *= inv;
@@ -1059,7 +1151,7 @@ __global__ __launch_bounds__(ATT_WAVES * 64 * (FUSE_OUT ? 2 : 1), 4) void dec_at
     for (int rr = 0; rr < NR; ++rr) {
       if (!live_rr[rr]) continue;
       const int br = slot_meta[4 * ((int)blockIdx.y + rr * gy)];
-      store_result(out_heads + ((long)h * MB + br) * D_MODEL + threadIdx.x, acc[rr]);
+      store_result(out_heads + ((long)(SPLIT ? h * nsplit + sp : h) * MB + br) * D_MODEL + threadIdx.x, acc[rr]);
     }
   }
   VX_STAMP(6, 4);
@@ -1355,7 +1447,10 @@ bool launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias
                      const int* slot_meta, float* xp_out, float* part_o, float* part_ml, int nsplit, int batch,
                      const float* wo_heads, float* out_heads, hipStream_t s) {
   if (splitk == SK_QKV_BALANCED) {         // 8 slabs of q, 4 of k / v (skinny_qkv_bal_kernel)
-    if (wo_heads && nsplit == 1)
+    if (wo_heads && nsplit > 1)           // fused out_proj with context splits (5 .. 16 rows): slabs h * nsplit + sp, weighed by dec_reduce_ln_split
+      hipLaunchKernelGGL((dec_attn_kernel<true, SK_QKV_BALANCED, true>), dim3(N_HEAD, (batch + 1) / 2, nsplit), dim3(ATT_WAVES * 64 * 2), 0, s, kc, vc,
+                         slot_meta, Tmax, batch, nsplit, 0, qkv_partial, qkv_bias, xp_out, part_o, part_ml, wo_heads, out_heads);
+    else if (wo_heads && nsplit == 1)
       hipLaunchKernelGGL((dec_attn_kernel<true, SK_QKV_BALANCED>), dim3(N_HEAD, (batch + 1) / 2, 1), dim3(ATT_WAVES * 64 * 2), 0, s, kc, vc, slot_meta,
                          Tmax, batch, 1, 0, qkv_partial, qkv_bias, xp_out, part_o, part_ml, wo_heads, out_heads);
     else
@@ -1364,7 +1459,10 @@ bool launch_dec_attn(const float* qkv_partial, int splitk, const float* qkv_bias
     return true;
   }
   if (splitk != 4) return false;           // the QKV split-K factor is compiled in
-  if (wo_heads && nsplit == 1)
+  if (wo_heads && nsplit > 1)
+    hipLaunchKernelGGL((dec_attn_kernel<true, 4, true>), dim3(N_HEAD, (batch + 1) / 2, nsplit), dim3(ATT_WAVES * 64 * 2), 0, s, kc, vc, slot_meta,
+                       Tmax, batch, nsplit, 0, qkv_partial, qkv_bias, xp_out, part_o, part_ml, wo_heads, out_heads);
+  else if (wo_heads && nsplit == 1)
     hipLaunchKernelGGL((dec_attn_kernel<true, 4>), dim3(N_HEAD, (batch + 1) / 2, 1), dim3(ATT_WAVES * 64 * 2), 0, s, kc, vc, slot_meta,
                        Tmax, batch, 1, 0, qkv_partial, qkv_bias, xp_out, part_o, part_ml, wo_heads, out_heads);
   else

@@ -392,7 +392,20 @@ int ar_prefill(vx_ctx* c, const vx_batch* b, int r0, int nb, int beams = 1) {
   // ~500 / ~1300 (profiles/r06_sb_sweep2.txt): 5 rows 6 -> 3 splits -3.5 %, 8 rows 4 -> 2 splits -3 % / -0.6 % of the AR phase, 12 and 16 rows
   // stay at 2; one split (the fused out_proj) only pays from 17 rows up
   if (nrows > SB_ROWS && nrows <= 16) c->nsplit = std::max(2, 256 / (nrows * N_HEAD));
-  if (c->att_nsplit_force > 0) c->nsplit = c->att_nsplit_force;       // measurement switch (tools/gpu_call.sh sb_sweep)
+  // 8 .. 16 rows (round 6, profiles/r06_fuse_split_sweep.txt): out_proj folded into dec_attn WITH context splits -- the combine moves behind the
+  // head's W_o slice (decode.hip dec_attn_kernel<true, *, true>, dec_reduce_ln_split_kernel), two launches per layer fewer.  The fused
+  // kernel runs two rows per 16-wave workgroup: as many splits (<= 4) as keep 16 heads x row pairs x splits inside ONE round of the 256 CUs
+  // (8 rows: 4, 9 .. 10: 3, 11 .. 16: 2; AR phase -2.7 % at 8 rows / context ~1000, -7 % at 10 rows, -5.5 % at 12, -4.6 % at 16).  5 .. 7 rows:
+  // too few workgroups either way, the unfused chain stays (5 rows: 297 vs 299 ms, 6 rows: 302 vs 302).
+  c->split_fused = false;
+  if (c->fuse_out && c->fuse_split == 1 && nrows >= 8 && nrows <= 16) {
+    const int ns = std::min(4, 256 / (N_HEAD * ((nrows + 1) / 2)));
+    if (ns >= 2) { c->nsplit = ns; c->split_fused = true; }
+  }
+  if (c->att_nsplit_force > 0) {                                      // measurement switches (tools/gpu_call.sh sb_sweep, tools/fuse_split_sweep.sh)
+    c->nsplit = c->att_nsplit_force;
+    c->split_fused = c->fuse_out && c->fuse_split != 0 && nrows > SB_ROWS && c->nsplit >= 2 && c->nsplit <= 4;
+  }
   // the small-batch chain compiles the split counts in (decode.hip): taken only for a combination that is instantiated
   c->sb_chain = false;
   if (c->sb_fuse && nrows <= SB_ROWS) {
@@ -556,13 +569,16 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
       if (c->qkv_bal) launch_skinny_qkv_balanced(L.in_wp, c->xp, c->p_qkv, st);
       else launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, st, true);
     }
-    const bool fused = c->fuse_out && c->nsplit == 1;
+    // out_proj inside dec_attn: one context split (17 .. 32 rows), or 2 .. 4 splits with the combine moved behind W_o (5 .. 16 rows, round 6)
+    const bool fused = c->fuse_out && (c->nsplit == 1 || c->split_fused);
     {
       ProfScope ps(c, 0);
       LAUNCH(launch_dec_attn(c->p_qkv, c->qkv_bal ? SK_QKV_BALANCED : SK_QKV, L.in_b, c->kc + l * cache_layer, c->vc + l * cache_layer, c->Tmax, c->slot_meta,
                       c->xp_att, c->part_o, c->part_ml, c->nsplit, nb, fused ? L.out_wh : nullptr, c->p_oh, st));
     }
-    if (fused) {
+    if (fused && c->nsplit > 1) {
+      LAUNCH(launch_dec_reduce_ln_split(c->p_oh, c->part_ml, c->nsplit, L.out_b, c->dh, c->dh, L.n2_w, L.n2_b, c->xp, nb, st));
+    } else if (fused) {
       launch_dec_reduce_ln_pack(c->p_oh, N_HEAD, D_MODEL, L.out_b, c->dh, c->dh, L.n2_w, L.n2_b, c->xp, nb, st);
     } else {
       if (c->nsplit > 1) launch_dec_attn_combine(c->part_o, c->part_ml, c->nsplit, c->active, c->xp_att, nb, st);
@@ -697,7 +713,7 @@ int ar_generate(vx_ctx* c, const vx_batch* b, const vx_sampling* s, int r0, int 
     }
   }
   char sig[160];
-  snprintf(sig, sizeof sig, "b%d ns%d c%d%d k%d t%a u%d f%d l%d", nb, c->nsplit, (int)c->sb_chain, (int)c->sb_qkv, sa.top_k, sa.temperature,
+  snprintf(sig, sizeof sig, "b%d ns%d c%d%d%d k%d t%a u%d f%d l%d", nb, c->nsplit, (int)c->sb_chain, (int)c->sb_qkv, (int)c->split_fused, sa.top_k, sa.temperature,
            sa.uniforms != nullptr, sa.force_eos_at, sa.sum_logp != nullptr);
   const int sync_every = s->sync_every > 0 ? s->sync_every : 8;
   // with a forced EOS every row is inactive after force_eos_at steps: do not run on to the next host poll

@@ -136,6 +136,8 @@ struct vx_ctx {
   bool nar_trim = true;            // last NAR layer computes only the generated rows (VX_NAR_TRIM=1; engine.hip struct Trim)
   bool balance_rows = true;        // dec_attn launch order pairs long with short contexts per CU (VX_BALANCE_ROWS=0: batch order)
   bool fuse_out = true;            // out_proj folded into dec_attn when nsplit == 1 (VX_FUSE_OUT=0: separate skinny GEMM)
+  int fuse_split = 1;              // ... and, 8 .. 16 rows, with 2 .. 4 context splits: slabs per (head, split) weighed by the consumer (VX_FUSE_SPLIT=0: dec_attn | combine | out_proj; 2: whenever VX_ATT_NSPLIT forces 2 .. 4 splits)
+  bool split_fused = false;        // decided per micro-batch by the prefill
   float *d_logits = nullptr, *d_uniforms = nullptr, *sum_logp = nullptr;
   long uniforms_cap = 0;
   int *cur_tok = nullptr, *cur_pos = nullptr, *ctx_len = nullptr, *n_gen = nullptr, *active = nullptr,

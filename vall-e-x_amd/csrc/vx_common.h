@@ -178,6 +178,8 @@ constexpr int SK_QKV_BAL_Q = 8, SK_QKV_BAL_KV = 4;
 constexpr int SK_QKV_BALANCED = SK_QKV_BAL_Q * 10 + SK_QKV_BAL_KV;
 void launch_skinny_qkv_balanced(const float* Wp, const float* xp, float* partial, hipStream_t s);   // 512 workgroups: q in 8 K slices, k / v in 4 (default since round 5)
 // h[b] = (resid? resid[b] : 0) + sum_ks partial[ks][b] + bias ; xp = pack(LN(h)*g+b)   (N = 1024)
+bool launch_dec_reduce_ln_split(const float* slabs, const float* part_ml, int nsplit, const float* bias, const float* resid, float* h,
+                                const float* g, const float* b, float* xp, int batch, hipStream_t s);      // consumer of the fused out_proj with context splits (2 .. 4)
 void launch_dec_reduce_ln_pack(const float* partial, int splitk, int npad, const float* bias, const float* resid,
                                float* h, const float* g, const float* b, float* xp, int batch, hipStream_t s);
 // linear1 with fused bias+ReLU+pack on 16-row tiles (v_mfma_f32_16x16x4_f32), 256 workgroups, no split-K
