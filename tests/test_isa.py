@@ -92,7 +92,7 @@ def metadata(lines, name_substr, key):
 
 
 def test_fused_dec_attn_reaches_its_first_requests_without_a_round_trip(asm):
-    body = kernel_body(asm("decode.hip"), r"_ZN2vx15dec_attn_kernelILb1ELi4EEE")
+    body = kernel_body(asm("decode.hip"), r"_ZN2vx15dec_attn_kernelILb1ELi4ELb0EEE")
     # with kernarg preload the hardware enters 256 bytes behind the symbol: skip the compatibility header (s_load ... s_branch)
     entry = next(i for i, ln in enumerate(body) if ln.startswith("s_branch")) + 1
     head = body[entry:]
@@ -115,7 +115,7 @@ def test_decode_gemms_request_a_whole_round_before_their_first_mfma(asm):
         assert sum(" nt" in ln for ln in loads) >= n_nt, (name, "the weight stream must be non-temporal")
         assert metadata(lines, name, "private_segment_fixed_size") == 0, name
     # the streaming loop of dec_attn keeps a tile of each of K and V in flight per iteration, all of it non-temporal
-    stream = max(loops(kernel_body(lines, r"_ZN2vx15dec_attn_kernelILb1ELi4EEE")), key=len)
+    stream = max(loops(kernel_body(lines, r"_ZN2vx15dec_attn_kernelILb1ELi4ELb0EEE")), key=len)
     ld = [ln for ln in stream if ln.startswith("global_load_dwordx4")]
     assert len(ld) == 16 and all(" nt" in ln for ln in ld), ld
     assert count(stream, r"s_barrier") == 0 and count(stream, r"ds_") == 0          # q . k through DPP row sums: no LDS, no barrier

@@ -59,7 +59,7 @@ def test_committed_resource_report_shows_no_spills():
     assert len(rows) >= 50
     assert all(r["scratch"] == 0 for r in rows.values()), [n for n, r in rows.items() if r["scratch"]]
     assert rows["gemm_f16x2_kernel<256, 256, 2, 0> (gemm_f16x2)"]["lds"] == 131072       # one 8-wave workgroup per CU
-    assert rows["attn_full_h2_kernel<0> (attn_full_h2)"]["occ"] == 2 and rows["dec_attn_kernel<true, 4> (decode)"]["occ"] == 4
+    assert rows["attn_full_h2_kernel<0> (attn_full_h2)"]["occ"] == 2 and rows["dec_attn_kernel<true, 4, false> (decode)"]["occ"] == 4 and rows["dec_attn_kernel<true, 84, true> (decode)"]["occ"] == 4
     # the fused small-batch attention holds ONE 8-wave workgroup per CU (its grid is sized for one round, engine.hip)
     assert rows["dec_attn_qkv_kernel<8, 8> (decode)"]["occ"] == 2
 
