@@ -569,7 +569,7 @@ void ar_step_launches(vx_ctx* c, const SampleArgs* sa) {
       if (c->qkv_bal) launch_skinny_qkv_balanced(L.in_wp, c->xp, c->p_qkv, st);
       else launch_skinny_gemm(L.in_wp, c->xp, c->p_qkv, 3 * D_MODEL, D_MODEL, SK_QKV, st, true);
     }
-    // out_proj inside dec_attn: one context split (17 .. 32 rows), or 2 .. 4 splits with the combine moved behind W_o (5 .. 16 rows, round 6)
+    // out_proj inside dec_attn: one context split (17 .. 32 rows), or 2 .. 4 splits with the combine moved behind W_o (8 .. 16 rows, round 6)
     const bool fused = c->fuse_out && (c->nsplit == 1 || c->split_fused);
     {
       ProfScope ps(c, 0);

@@ -153,7 +153,7 @@ int vx_finalize_weights(vx_ctx* c) {
   static_assert(SK_QKV_BAL_Q == 8 && SK_QKV_BAL_KV == SK_QKV, "skinny_qkv_bal_kernel writes 8 q slabs and SK_QKV k / v slabs into p_qkv");
   if ((e = dev_alloc(c, &c->p_qkv, (size_t)std::max(SK_QKV, SK_QKV_BAL_Q) * MB * 3 * d))) return e;
   if ((e = dev_alloc(c, &c->p_o, (size_t)std::max(SK_OUT, SK_L2) * MB * d))) return e;
-  if ((e = dev_alloc(c, &c->p_oh, (size_t)4 * N_HEAD * MB * d))) return e;      // per-head slabs of the fused out_proj; x up to 4 context splits (5 .. 16 rows)
+  if ((e = dev_alloc(c, &c->p_oh, (size_t)4 * N_HEAD * MB * d))) return e;      // per-head slabs of the fused out_proj; x up to 4 context splits (8 .. 16 rows)
   if (const char* ev = getenv("VX_FUSE_OUT")) c->fuse_out = !(ev[0] == '0');
   // the fused dec_attn requests the first DEC_ATTN_TILE rows of every (slot, head) stream before it knows the context length
   if (c->Tmax < DEC_ATTN_TILE) c->fuse_out = false;
